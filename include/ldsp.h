@@ -61,6 +61,12 @@ const char* ldsp_last_error_string(void);
 /* Average duration in ms of the launches issued by the last ldsp_*_run call,
  * measured with hipEvents recorded on the context stream (timing must have
  * been enabled; synchronises the stream). */
+/* Options: "cusp_direct" = 1 evaluates CUSP/ZAC as direct-form FIR (slow
+ * comparator for the closed-form recursions), 0 (default) = recursions. */
+int ldsp_ctx_set_option(ldsp_ctx* ctx, const char* key, int64_t value);
+/* sizeof() of the ABI structs as compiled: 0 icpc_params, 1 icpc_out,
+ * 2 sipm_params, 3 sipm_out, 4 trig_out (binding self-check). */
+int64_t ldsp_abi_sizeof(int which);
 int ldsp_ctx_enable_timing(ldsp_ctx* ctx, int on);
 int ldsp_ctx_last_kernel_ms(ldsp_ctx* ctx, float* ms);
 
@@ -167,6 +173,10 @@ typedef struct {
   float* inTrace_intersect;
   int32_t* inTrace_n;
   int32_t *n_sat_low, *n_sat_high, *n_sat_low_cons, *n_sat_high_cons;
+  /* elements between consecutive traces in every column: 1 (or 0) = separate
+   * contiguous columns; LDSP_ICPC_NCOLS = the columns interleave into one
+   * row-major [n][48] table (one contiguous block for the multi-GPU gather). */
+  int64_t stride;
 } ldsp_icpc_out;
 #define LDSP_ICPC_NCOLS 48 /* computed 4-byte columns above */
 

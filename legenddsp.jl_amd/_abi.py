@@ -89,7 +89,7 @@ assert len(ICPC_COLS) == 48
 
 
 class IcpcOut(C.Structure):
-    _fields_ = [(c, C.c_void_p) for c in ICPC_COLS]
+    _fields_ = [(c, C.c_void_p) for c in ICPC_COLS] + [("stride", C.c_int64)]
 
 
 class SipmParams(C.Structure):

@@ -1,0 +1,92 @@
+// icpc_dev.hpp — device-resident parameter block of the fused dsp_icpc kernel.
+// Built on the host from ldsp_icpc_params (ldsp_api.cpp: lower_icpc_dev) and
+// uploaded once per run call; read through scalar loads in the kernel.
+#pragma once
+#include <stdint.h>
+#include "../../include/ldsp.h"
+
+namespace ldsp {
+
+constexpr int SPT_HOST = 32;  // samples per thread of the trace kernels (== ldsp::SPT)
+
+struct TrapDev {
+  int32_t n1, g, n2, flen;  // navg, ngap, navg2, total length
+  float inv1, inv2;         // 1/navg, 1/navg2
+};
+
+// LSQ polynomial estimator (PolynomialDNI): yhat(u) = sum_i y[i0+i] * sum_j B[i][j] u^j,
+// u = (p - i0 - c) * s_inv  (centred, scaled local coordinate)
+struct EstDev {
+  int32_t npts, deg;
+  float c, s_inv;
+  float B[LDSP_MAX_EST_PTS * (LDSP_MAX_EST_DEG + 1)];
+};
+
+// window statistics in index space: xi = i - ic, sum xi = 0, var_xi = (n^2-1)/12
+struct WinDev {
+  int32_t from, until;
+  double ic, inv_n, var_i;
+};
+
+// Closed-form CUSP / ZAC: all constants in float,
+// derived in double on the host.
+struct CuspZacDev {
+  int32_t Lf, lt, flat, f1, ltp;  // taps, rise length, flat, first fall tap, fall length Lf-f1
+  float q;                         // exp(-1/sigma)
+  float eps;                       // 1 - exp(-1/tau)
+  float sc_half_den;               // beta/Lf / (2 sinh(lt/sigma))
+  float sc;                        // beta/Lf
+  float q_lt, q_mlt1;              // q^lt, q^-(lt-1)
+  float q_ltp1, q_mltp;            // q^(ltp-1), q^-ltp
+  float w_last;                    // shape[Lf-1] * sc (tap that multiplies y[k] directly)
+  float rho_sc;                    // ZAC: -acusp/apar * beta/Lf (multiplies the parabola part)
+  float par_last;                  // ZAC: par[Lf-1]
+  int32_t is_zac;
+  int32_t _pad;
+};
+
+struct IcpcDev {
+  int32_t L, NT;
+  float t_first, dt, unit_per_us, inv_unit_per_us;
+  float sat_low, sat_high;
+  WinDev bl, tail, sgbl;
+  float pz_c;
+  double pz_c64;
+  TrapDev t0, t0inv, fixed[3], opt;
+  int32_t t0inv_same;  // t0inv trapezoid == t0 trapezoid (reuse by linearity)
+  int32_t t0_mintot, tx_mintot, intrace_mintot;
+  float t0_thr, intrace_nsigma;
+  EstDev int_est, sig_est;
+  float qdrift_d1, qdrift_d2, lq_d1, lq_d2;       // in samples
+  float trap_pickoff, cusp_pickoff, zac_pickoff;  // in samples
+  // Savitzky-Golay: correlation-form coefficients c[i] (out[k] = sum_i c[i] y[k+i])
+  int32_t sg_npts[3];
+  int32_t sg_same_02;  // a_100 filter == a_sg filter
+  float sg_c[3][LDSP_MAX_SG_PTS];
+  int32_t cur_from[4], cur_until[4];  // current window on the axes of sg[0..2] and of the plain derivative
+  CuspZacDev cusp, zac;
+  int32_t cz_shared;  // cusp and zac share sigma/flat/length/tau: one set of recursions
+  int32_t cusp_mode;  // 0 = direct-form FIR (comparator), 1 = closed-form recursions
+  const float* h_cusp; // device, true-convolution taps (mode 0)
+  const float* h_zac;
+};
+
+struct IcpcOutDev {
+  void* col[LDSP_ICPC_NCOLS];
+  int64_t stride;  // elements between consecutive traces (1 = SoA columns, 48 = one [n][48] table)
+};
+
+// column indices = order of ldsp_icpc_out
+enum IcpcCol {
+  C_blmean, C_blsigma, C_blslope, C_bloffset, C_tailmean, C_tailsigma, C_tailslope, C_tailoffset,
+  C_t0, C_t10, C_t50, C_t80, C_t90, C_t99, C_t50_current, C_drift_time,
+  C_tail_tau, C_tail_mean, C_tail_sigma, C_e_max, C_e_min,
+  C_e_10410, C_e_535, C_e_313, C_e_10410_inv, C_e_313_inv, C_t0_inv,
+  C_e_trap, C_e_cusp, C_e_zac, C_e_trap_max, C_e_cusp_max, C_e_zac_max,
+  C_t_trap_max, C_t_cusp_max, C_t_zac_max, C_qdrift, C_lq,
+  C_a_sg, C_a_60, C_a_100, C_a_raw, C_inTrace_intersect, C_inTrace_n,
+  C_n_sat_low, C_n_sat_high, C_n_sat_low_cons, C_n_sat_high_cons, C_NCOLS
+};
+static_assert(C_NCOLS == LDSP_ICPC_NCOLS, "column count");
+
+}  // namespace ldsp

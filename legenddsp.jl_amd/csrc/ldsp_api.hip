@@ -1,0 +1,348 @@
+// ldsp_api.hip — the C ABI of include/ldsp.h: context, host-side lowering of the
+// parameter blocks to device constants, launches.  No torch types, no CPU
+// compute fallback: every entry point either launches HIP kernels or fails.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ldsp.h"
+#include "host_math.hpp"
+#include "icpc_dev.hpp"
+
+namespace ldsp {
+hipError_t launch_icpc(const float* wf, int64_t n, int NT, const IcpcDev* dP, const IcpcOutDev& out, hipStream_t st);
+hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
+size_t icpc_smem_bytes(int NT);
+}  // namespace ldsp
+
+using namespace ldsp;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) return fail(LDSP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+struct ldsp_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // dsp_icpc parameter staging
+  ldsp_icpc_params icpc_last{};
+  bool icpc_valid = false;
+  int icpc_mode_built = -1;
+  IcpcDev icpc_host{};
+  IcpcDev* d_icpc = nullptr;
+  float* d_hc = nullptr;
+  float* d_hz = nullptr;
+  int cusp_direct = 0;
+  // timing
+  int timing = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int n_launches = 0;
+};
+
+extern "C" {
+
+int ldsp_abi_version(void) { return LDSP_ABI_VERSION; }
+
+int64_t ldsp_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(ldsp_icpc_params);
+    case 1: return sizeof(ldsp_icpc_out);
+    case 2: return sizeof(ldsp_sipm_params);
+    case 3: return sizeof(ldsp_sipm_out);
+    case 4: return sizeof(ldsp_trig_out);
+    default: return -1;
+  }
+}
+
+const char* ldsp_last_error_string(void) { return g_err.c_str(); }
+
+int ldsp_ctx_create(int device, ldsp_ctx** out) {
+  if (!out) return fail(LDSP_ERR_INVALID_ARG, "ldsp_ctx_create: out is NULL");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(LDSP_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  ldsp_ctx* c = new (std::nothrow) ldsp_ctx();
+  if (!c) return fail(LDSP_ERR_NOMEM, "out of host memory");
+  c->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  HIP_TRY(hipMalloc(&c->d_icpc, sizeof(IcpcDev)));
+  HIP_TRY(hipMalloc(&c->d_hc, sizeof(float) * LDSP_MAX_FIR_TAPS));
+  HIP_TRY(hipMalloc(&c->d_hz, sizeof(float) * LDSP_MAX_FIR_TAPS));
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+  *out = c;
+  return LDSP_OK;
+}
+
+int ldsp_ctx_destroy(ldsp_ctx* c) {
+  if (!c) return LDSP_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  hipFree(c->d_icpc); hipFree(c->d_hc); hipFree(c->d_hz);
+  hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
+  hipStreamDestroy(c->own_stream);
+  delete c;
+  return LDSP_OK;
+}
+
+int ldsp_ctx_set_stream(ldsp_ctx* c, void* s) {
+  if (!c) return fail(LDSP_ERR_INVALID_ARG, "ctx is NULL");
+  c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+  return LDSP_OK;
+}
+
+int ldsp_ctx_synchronize(ldsp_ctx* c) {
+  if (!c) return fail(LDSP_ERR_INVALID_ARG, "ctx is NULL");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return LDSP_OK;
+}
+
+int ldsp_ctx_set_option(ldsp_ctx* c, const char* key, int64_t value) {
+  if (!c || !key) return fail(LDSP_ERR_INVALID_ARG, "ctx/key is NULL");
+  if (!strcmp(key, "cusp_direct")) { c->cusp_direct = value != 0; return LDSP_OK; }
+  return fail(LDSP_ERR_INVALID_ARG, "unknown option '%s'", key);
+}
+
+int ldsp_ctx_enable_timing(ldsp_ctx* c, int on) {
+  if (!c) return fail(LDSP_ERR_INVALID_ARG, "ctx is NULL");
+  c->timing = on != 0;
+  return LDSP_OK;
+}
+
+int ldsp_ctx_last_kernel_ms(ldsp_ctx* c, float* ms) {
+  if (!c || !ms) return fail(LDSP_ERR_INVALID_ARG, "ctx/ms is NULL");
+  if (!c->timing || c->n_launches == 0) return fail(LDSP_ERR_INVALID_ARG, "timing not enabled or nothing launched");
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  float t = 0;
+  HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
+  *ms = t / (float)c->n_launches;
+  return LDSP_OK;
+}
+
+int ldsp_cusp_coeffs(const ldsp_cuspzac* p, double* h) {
+  if (!p || !h || !hm::cusp_shape_ok(*p)) return fail(LDSP_ERR_INVALID_ARG, "bad CUSP parameters");
+  std::vector<double> v;
+  hm::cuspzac_taps(*p, false, v);
+  memcpy(h, v.data(), sizeof(double) * v.size());
+  return LDSP_OK;
+}
+int ldsp_zac_coeffs(const ldsp_cuspzac* p, double* h) {
+  if (!p || !h || !hm::cusp_shape_ok(*p)) return fail(LDSP_ERR_INVALID_ARG, "bad ZAC parameters");
+  std::vector<double> v;
+  hm::cuspzac_taps(*p, true, v);
+  memcpy(h, v.data(), sizeof(double) * v.size());
+  return LDSP_OK;
+}
+int ldsp_sg_coeffs(int32_t npts, int32_t degree, int32_t derivative, double* h) {
+  std::vector<double> c;
+  if (!h || !hm::sg_corr_coeffs(npts, degree, derivative, c)) return fail(LDSP_ERR_INVALID_ARG, "bad Savitzky-Golay parameters");
+  for (int i = 0; i < npts; ++i) h[npts - 1 - i] = c[i];  // true-convolution order
+  return LDSP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// lowering ldsp_icpc_params -> IcpcDev
+
+static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+static bool check_window(int from, int until, int n) { return 0 <= from && from <= until && until <= n - 1; }
+
+static WinDev make_win(int from, int until) {
+  WinDev w;
+  w.from = from; w.until = until;
+  double n = (double)(until - from + 1);
+  w.ic = 0.5 * ((double)from + (double)until);
+  w.inv_n = 1.0 / n;
+  w.var_i = (n * n - 1.0) / 12.0;
+  return w;
+}
+static TrapDev make_trap(const ldsp_trap& t) {
+  TrapDev d;
+  d.n1 = t.navg; d.g = t.ngap; d.n2 = t.navg2; d.flen = t.navg + t.ngap + t.navg2;
+  d.inv1 = (float)(1.0 / t.navg); d.inv2 = (float)(1.0 / t.navg2);
+  return d;
+}
+static bool trap_ok(const ldsp_trap& t, int L) { return t.navg >= 1 && t.navg2 >= 1 && t.ngap >= 0 && t.navg + t.ngap + t.navg2 <= L; }
+
+static bool make_est(const ldsp_dni& e, EstDev& d) {
+  if (e.npts < 1 || e.npts > LDSP_MAX_EST_PTS || e.degree < 0 || e.degree > LDSP_MAX_EST_DEG || e.degree >= e.npts) return false;
+  std::vector<double> B;
+  double c, s;
+  if (!hm::lsq_basis(e.npts, e.degree, B, c, s)) return false;
+  d.npts = e.npts; d.deg = e.degree; d.c = (float)c; d.s_inv = (float)(1.0 / s);
+  memset(d.B, 0, sizeof d.B);
+  for (int i = 0; i < e.npts; ++i)
+    for (int j = 0; j <= e.degree; ++j) d.B[i * (LDSP_MAX_EST_DEG + 1) + j] = (float)B[(size_t)i * (e.degree + 1) + j];
+  return true;
+}
+
+static void make_cuspzac(const ldsp_cuspzac& p, bool zac, CuspZacDev& d) {
+  hm::CuspShape g = hm::cusp_geometry(p);
+  memset(&d, 0, sizeof d);
+  d.Lf = g.Lf; d.lt = g.lt; d.flat = g.flat; d.f1 = g.f1; d.ltp = g.ltp;
+  const double q = std::exp(-1.0 / p.sigma), sc = p.beta / (double)p.length;
+  d.q = (float)q;
+  d.eps = (float)(-std::expm1(-1.0 / p.tau));
+  d.sc = (float)sc;
+  d.sc_half_den = (float)(sc * 0.5 / g.den);
+  d.q_lt = (float)std::exp(-(double)g.lt / p.sigma);
+  d.q_mlt1 = (float)std::exp((double)(g.lt - 1) / p.sigma);
+  d.q_ltp1 = (float)std::exp(-(double)(g.ltp - 1) / p.sigma);
+  d.q_mltp = (float)std::exp((double)g.ltp / p.sigma);
+  std::vector<double> cusp, par;
+  hm::cusp_and_par(p, cusp, par);
+  double apar = 0, acusp = 0;
+  for (int j = 0; j < g.Lf; ++j) { apar += par[j]; acusp += cusp[j]; }
+  double rho = zac ? acusp / apar : 0.0;
+  d.w_last = (float)(sc * (cusp[g.Lf - 1] - rho * par[g.Lf - 1]));
+  d.rho_sc = (float)(rho * sc);
+  d.par_last = (float)par[g.Lf - 1];
+  d.is_zac = zac;
+}
+
+static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, IcpcDev& d, std::vector<float>& hc, std::vector<float>& hz) {
+  memset(&d, 0, sizeof d);
+  const int L = p.L;
+  if (L < 64 || L > LDSP_MAX_L) return fail(LDSP_ERR_UNSUPPORTED, "trace length %d outside [64, %d]", L, LDSP_MAX_L);
+  if (!(p.dt > 0) || !(p.unit_per_us > 0)) return fail(LDSP_ERR_INVALID_ARG, "dt and unit_per_us must be positive");
+  d.L = L;
+  d.NT = round_up((L + SPT_HOST - 1) / SPT_HOST, 64);
+  d.t_first = (float)p.t_first; d.dt = (float)p.dt;
+  d.unit_per_us = (float)p.unit_per_us; d.inv_unit_per_us = (float)(1.0 / p.unit_per_us);
+  d.sat_low = (float)p.sat_low; d.sat_high = (float)p.sat_high;
+  if (!check_window(p.bl_from, p.bl_until, L)) return fail(LDSP_ERR_WINDOW, "bl_window [%d,%d] outside trace", p.bl_from, p.bl_until);
+  if (!check_window(p.tail_from, p.tail_until, L)) return fail(LDSP_ERR_WINDOW, "tail_window [%d,%d] outside trace", p.tail_from, p.tail_until);
+  d.bl = make_win(p.bl_from, p.bl_until);
+  d.tail = make_win(p.tail_from, p.tail_until);
+  d.pz_c = (float)p.pz_c; d.pz_c64 = p.pz_c;
+  const ldsp_trap* traps[6] = {&p.t0_trap, &p.t0inv_trap, &p.trap_fixed[0], &p.trap_fixed[1], &p.trap_fixed[2], &p.trap_opt};
+  for (auto t : traps)
+    if (!trap_ok(*t, L)) return fail(LDSP_ERR_WINDOW, "trapezoid (%d,%d,%d) does not fit a trace of %d samples", t->navg, t->ngap, t->navg2, L);
+  d.t0 = make_trap(p.t0_trap); d.t0inv = make_trap(p.t0inv_trap);
+  for (int i = 0; i < 3; ++i) d.fixed[i] = make_trap(p.trap_fixed[i]);
+  d.opt = make_trap(p.trap_opt);
+  d.t0inv_same = !memcmp(&p.t0_trap, &p.t0inv_trap, sizeof(ldsp_trap));
+  if (p.t0_mintot < 1 || p.tx_mintot < 1 || p.intrace_mintot < 1) return fail(LDSP_ERR_INVALID_ARG, "mintot values must be >= 1 sample");
+  d.t0_mintot = p.t0_mintot; d.tx_mintot = p.tx_mintot; d.intrace_mintot = p.intrace_mintot;
+  d.t0_thr = (float)p.t0_threshold; d.intrace_nsigma = (float)p.intrace_nsigma;
+  if (!make_est(p.int_est, d.int_est) || !make_est(p.sig_est, d.sig_est))
+    return fail(LDSP_ERR_UNSUPPORTED, "PolynomialDNI window/degree outside the built limits (%d pts, degree %d)", LDSP_MAX_EST_PTS, LDSP_MAX_EST_DEG);
+  d.qdrift_d1 = (float)(p.qdrift_d1 / p.dt); d.qdrift_d2 = (float)(p.qdrift_d2 / p.dt);
+  d.lq_d1 = (float)(p.lq_d1 / p.dt); d.lq_d2 = (float)(p.lq_d2 / p.dt);
+  d.trap_pickoff = (float)(p.trap_pickoff / p.dt);
+  d.cusp_pickoff = (float)(p.cusp_pickoff / p.dt);
+  d.zac_pickoff = (float)(p.zac_pickoff / p.dt);
+  for (int f = 0; f < 3; ++f) {
+    const int np = p.sg_npts[f];
+    if (np < 1 || np > LDSP_MAX_SG_PTS || (np & 1) == 0 || np <= p.sg_degree || np > L)
+      return fail(LDSP_ERR_UNSUPPORTED, "Savitzky-Golay window of %d points (degree %d) unsupported", np, p.sg_degree);
+    std::vector<double> cc;
+    if (!hm::sg_corr_coeffs(np, p.sg_degree, 1, cc)) return fail(LDSP_ERR_INVALID_ARG, "Savitzky-Golay coefficients");
+    d.sg_npts[f] = np;
+    for (int i = 0; i < np; ++i) d.sg_c[f][i] = (float)cc[i];
+    const double tf = p.t_first + (np - 1) * p.dt;  // trailing alignment (A1)
+    d.cur_from[f] = (int)std::nearbyint((p.cur_left - tf) / p.dt);
+    d.cur_until[f] = (int)std::nearbyint((p.cur_right - tf) / p.dt);
+    if (!check_window(d.cur_from[f], d.cur_until[f], L - np + 1)) return fail(LDSP_ERR_WINDOW, "current_window outside the SG output axis");
+  }
+  d.sg_same_02 = d.sg_npts[0] == d.sg_npts[2];
+  d.cur_from[3] = (int)std::nearbyint((p.cur_left - p.t_first) / p.dt);
+  d.cur_until[3] = (int)std::nearbyint((p.cur_right - p.t_first) / p.dt);
+  if (!check_window(d.cur_from[3], d.cur_until[3], L)) return fail(LDSP_ERR_WINDOW, "current_window outside trace");
+  {
+    const int np = d.sg_npts[0];
+    const double tf = p.t_first + (np - 1) * p.dt;
+    int from = (int)std::nearbyint(((p.bl_left + tf) - tf) / p.dt);  // dsp_routines.jl:75
+    int until = (int)std::nearbyint((p.bl_right - tf) / p.dt);
+    if (!check_window(from, until, L - np + 1)) return fail(LDSP_ERR_WINDOW, "bl_window outside the SG output axis");
+    d.sgbl = make_win(from, until);
+  }
+  if (!hm::cusp_shape_ok(p.cusp) || !hm::cusp_shape_ok(p.zac) || p.cusp.length > L || p.zac.length > L ||
+      p.cusp.length > LDSP_MAX_FIR_TAPS || p.zac.length > LDSP_MAX_FIR_TAPS)
+    return fail(LDSP_ERR_WINDOW, "CUSP/ZAC filter does not fit the trace");
+  make_cuspzac(p.cusp, false, d.cusp);
+  make_cuspzac(p.zac, true, d.zac);
+  d.cz_shared = p.cusp.sigma == p.zac.sigma && p.cusp.flat == p.zac.flat && p.cusp.length == p.zac.length &&
+                p.cusp.tau == p.zac.tau && p.cusp.beta == p.zac.beta;
+  d.cusp_mode = cusp_direct ? 0 : 1;
+  std::vector<double> h;
+  hm::cuspzac_taps(p.cusp, false, h);
+  hc.assign(h.begin(), h.end());
+  hm::cuspzac_taps(p.zac, true, h);
+  hz.assign(h.begin(), h.end());
+  return LDSP_OK;
+}
+
+static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p) {
+  if (c->icpc_valid && c->icpc_mode_built == c->cusp_direct && !memcmp(&c->icpc_last, p, sizeof *p)) return LDSP_OK;
+  std::vector<float> hc, hz;
+  IcpcDev d;
+  int rc = lower_icpc_dev(*p, c->cusp_direct, d, hc, hz);
+  if (rc) return rc;
+  d.h_cusp = c->d_hc; d.h_zac = c->d_hz;
+  c->icpc_host = d;
+  HIP_TRY(hipMemcpyAsync(c->d_icpc, &c->icpc_host, sizeof(IcpcDev), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_hc, hc.data(), sizeof(float) * hc.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_hz, hz.data(), sizeof(float) * hz.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // staging vectors die at return
+  c->icpc_last = *p; c->icpc_valid = true; c->icpc_mode_built = c->cusp_direct;
+  return LDSP_OK;
+}
+
+extern "C" {
+
+int ldsp_icpc_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_params* p, const ldsp_icpc_out* out) {
+  if (!c || !p || !out) return fail(LDSP_ERR_INVALID_ARG, "ldsp_icpc_run: NULL argument");
+  if (n < 0 || n > 0x7fffffffLL) return fail(LDSP_ERR_INVALID_ARG, "n = %lld out of range", (long long)n);
+  if (n == 0) return LDSP_OK;
+  if (!wf) return fail(LDSP_ERR_INVALID_ARG, "waveform pointer is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = prepare_icpc(c, p);
+  if (rc) return rc;
+  IcpcOutDev od;
+  static_assert(sizeof(ldsp_icpc_out) == sizeof(void*) * LDSP_ICPC_NCOLS + sizeof(int64_t), "ldsp_icpc_out layout");
+  memcpy(od.col, out, sizeof(void*) * LDSP_ICPC_NCOLS);
+  od.stride = out->stride > 0 ? out->stride : 1;
+  if (icpc_smem_bytes(c->icpc_host.NT) > 160 * 1024) return fail(LDSP_ERR_UNSUPPORTED, "trace too long for the LDS-resident kernel");
+  if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->d_icpc, od, c->stream));
+  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; }
+  return LDSP_OK;
+}
+
+int ldsp_icpc_pz_trap_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_params* p, float* blmean, float* e_10410) {
+  if (!c || !p || !blmean || !e_10410) return fail(LDSP_ERR_INVALID_ARG, "ldsp_icpc_pz_trap_run: NULL argument");
+  if (n < 0 || n > 0x7fffffffLL) return fail(LDSP_ERR_INVALID_ARG, "n = %lld out of range", (long long)n);
+  if (n == 0) return LDSP_OK;
+  if (!wf) return fail(LDSP_ERR_INVALID_ARG, "waveform pointer is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = prepare_icpc(c, p);
+  if (rc) return rc;
+  if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(launch_pz_trap(wf, n, c->icpc_host.NT, c->d_icpc, blmean, e_10410, c->stream));
+  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; }
+  return LDSP_OK;
+}
+
+}  // extern "C"
