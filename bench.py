@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the dsp_icpc hot path on N MI355X GPUs of one node.
+
+A "step" is one pass of the fused dsp_icpc chain (reference src/dsp_icpc.jl:62-230,
+full chain incl. CUSP/ZAC + extremestats + Intersect family = BASELINE config 3)
+over one batch of synthetic HPGe traces that is already resident in HBM.
+  N = 1 : 1 M x 8192-sample float32 traces on one GPU (config 3).
+  N > 1 : each rank owns its own 1 M-trace shard (weak scaling), runs the same
+          kernel and the [n,48] output shards are gathered to rank 0 with one
+          RCCL gather inside the timed region (config 4 shape).
+Prints ONE JSON line (rank 0).  `--workload pz_trap` times BASELINE config 2
+(blmean -> shift -> InvCR -> Trap(10us,4us) -> max) instead.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import legenddsp_jl_amd as ldsp  # noqa: E402
+from legenddsp_jl_amd import dist as ldist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md chip table)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=1_000_000, help="traces per GPU")
+    ap.add_argument("--L", type=int, default=8192)
+    ap.add_argument("--workload", choices=["icpc", "pz_trap"], default="icpc")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="traces timed on the host cores (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    n, L = args.n, args.L
+    dt = 16.0 * (8192 / L) if L < 8192 else 16.0  # 4096-sample plumbing config needs 32 ns
+    cfg = ldsp.reference_test_icpc_config() if L >= 8192 else ldsp.plumbing_icpc_config_4096()
+    params = ldsp.lower_icpc(cfg, 500 * ldsp.us, {}, L, 0.0, dt)
+
+    # synthetic input, generated directly in HBM (excluded from timing)
+    wf = torch.empty((n, L), dtype=torch.float32, device=dev)
+    ldsp.synth.hpge_batch(n, L, device=dev, out=wf, first_trace=rank * n)
+    ctx = ldsp.Context(dev.index)
+    ctx.enable_timing(True)
+    ncol = len(ldsp._abi.ICPC_COLS)
+    out = torch.empty((n, ncol), dtype=torch.float32, device=dev) if args.workload == "icpc" else \
+        torch.empty((2, n), dtype=torch.float32, device=dev)
+
+    def step():
+        if args.workload == "icpc":
+            ldsp.icpc_run(wf, params, ctx, out=out)
+            if world > 1:
+                ldist.gather_table(out, n * world, dst=0)
+        else:
+            ldsp.icpc_pz_trap_run(wf, params, ctx, out=out)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if rank == 0 and world == 1:
+            pass
+    fence()
+    elapsed = time.perf_counter() - t0
+    # per-launch duration of the dominant kernel, HIP events on the launch stream
+    for _ in range(3):
+        if args.workload == "icpc":
+            ldsp.icpc_run(wf, params, ctx, out=out)
+        else:
+            ldsp.icpc_pz_trap_run(wf, params, ctx, out=out)
+        kernel_ms.append(ctx.last_kernel_ms())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total = n * world * args.steps
+        wps = total / elapsed
+        kms = sum(kernel_ms) / len(kernel_ms)
+        bytes_per_trace = 4 * L + (4 * ncol if args.workload == "icpc" else 8)
+        achieved = n * bytes_per_trace / (kms * 1e-3) / 1e9
+        res = {
+            "metric": "waveforms/s, full dsp_icpc chain, 8192-sample f32" if args.workload == "icpc"
+            else "waveforms/s, pole-zero + trapezoid sub-chain, 8192-sample f32",
+            "value": wps, "unit": "waveforms/s",
+            "msamples_per_s": wps * L / 1e6,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("BASELINE config 3: 1M x 8192 f32, full dsp_icpc chain" if args.workload == "icpc"
+                                    else "BASELINE config 2: 1M x 8192 f32, pole-zero + trapezoid"),
+                       "traces_per_gpu": n, "samples": L, "dt_ns": dt,
+                       "dsp_config": "reference test/test_dsp_icpc.jl:50-161", "tau_us": 500,
+                       "gather": "rccl gather of [n,48] f32 to rank 0" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "icpc_kernel" if args.workload == "icpc" else "pz_trap_kernel",
+                         "kernel_ms": kms, "algorithmic_bytes_per_trace": bytes_per_trace},
+        }
+        if world == 1 and args.cpu_sample > 0 and args.workload == "icpc":
+            from oracle import oracle as orc  # checker / CPU baseline only
+            orc.build()
+            m = min(args.cpu_sample, n)
+            host = wf[:m].cpu().numpy()
+            cores = min(os.cpu_count() or 1, 16)
+            orc.dsp_icpc(host[:cores], params, nthreads=cores)  # warm-up (thread pool, LSQ bases)
+            t1 = time.perf_counter()
+            orc.dsp_icpc(host, params, nthreads=cores)
+            cpu_t = time.perf_counter() - t1
+            res["cpu_baseline"] = {
+                "value": m / cpu_t, "unit": "waveforms/s", "cores": cores, "kind": "port",
+                "sample": f"first {m} traces of the same batch, float64 CPU restatement (oracle/ldsp_oracle.c), "
+                          f"OpenMP over traces, direct-form CUSP/ZAC; proxy for the single-threaded Julia reference",
+            }
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

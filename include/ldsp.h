@@ -53,20 +53,22 @@ typedef struct ldsp_ctx ldsp_ctx; /* opaque: device id, stream, parameter stagin
 int ldsp_abi_version(void);
 int ldsp_ctx_create(int device, ldsp_ctx** out);
 int ldsp_ctx_destroy(ldsp_ctx* ctx);
-/* Use an existing hipStream_t (e.g. torch's current stream); NULL = the
- * context's own stream. */
+/* Launch on an existing hipStream_t (e.g. torch's current stream).  NULL is the
+ * device's default (null) stream, exactly as in the HIP API. */
 int ldsp_ctx_set_stream(ldsp_ctx* ctx, void* hip_stream);
+/* Back to the context's own non-blocking stream (the initial state). */
+int ldsp_ctx_use_own_stream(ldsp_ctx* ctx);
 int ldsp_ctx_synchronize(ldsp_ctx* ctx);
 const char* ldsp_last_error_string(void);
-/* Average duration in ms of the launches issued by the last ldsp_*_run call,
- * measured with hipEvents recorded on the context stream (timing must have
- * been enabled; synchronises the stream). */
 /* Options: "cusp_direct" = 1 evaluates CUSP/ZAC as direct-form FIR (slow
  * comparator for the closed-form recursions), 0 (default) = recursions. */
 int ldsp_ctx_set_option(ldsp_ctx* ctx, const char* key, int64_t value);
 /* sizeof() of the ABI structs as compiled: 0 icpc_params, 1 icpc_out,
  * 2 sipm_params, 3 sipm_out, 4 trig_out (binding self-check). */
 int64_t ldsp_abi_sizeof(int which);
+/* Average duration in ms of the launches issued by the last ldsp_*_run call,
+ * measured with hipEvents recorded on the context stream (timing must have
+ * been enabled; synchronises on the closing event). */
 int ldsp_ctx_enable_timing(ldsp_ctx* ctx, int on);
 int ldsp_ctx_last_kernel_ms(ldsp_ctx* ctx, float* ms);
 

@@ -9,7 +9,8 @@ compute entry point raises if the HIP library is missing.
 from . import _abi, _lib, synth
 from ._lib import Context, LdspError, build, default_context
 from .config import (DSPConfig, PropDict, ClosedInterval, StepRange, get_fltpars, lower_icpc, lower_sipm,
-                     reference_test_icpc_config, reference_test_sipm_config, ns, us, ms, WindowError)
+                     reference_test_icpc_config, reference_test_sipm_config, plumbing_icpc_config_4096,
+                     ns, us, ms, WindowError)
 from .routines import ArrayOfRDWaveforms, Table, dsp_icpc, icpc_run, icpc_pz_trap_run, table_columns
 
 __all__ = [n for n in dir() if not n.startswith("_")]

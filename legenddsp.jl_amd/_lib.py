@@ -51,6 +51,7 @@ def _declare(lib):
     sig("ldsp_ctx_create", [C.c_int, C.POINTER(_VOIDP)])
     sig("ldsp_ctx_destroy", [_VOIDP])
     sig("ldsp_ctx_set_stream", [_VOIDP, _VOIDP])
+    sig("ldsp_ctx_use_own_stream", [_VOIDP])
     sig("ldsp_ctx_synchronize", [_VOIDP])
     sig("ldsp_ctx_set_option", [_VOIDP, C.c_char_p, _I64])
     sig("ldsp_ctx_enable_timing", [_VOIDP, C.c_int])
@@ -92,6 +93,7 @@ def _declare(lib):
 # every symbol include/ldsp.h declares (checked by tests/test_abi.py)
 DECLARED_SYMBOLS = [
     "ldsp_abi_version", "ldsp_abi_sizeof", "ldsp_ctx_create", "ldsp_ctx_destroy", "ldsp_ctx_set_stream",
+    "ldsp_ctx_use_own_stream",
     "ldsp_ctx_synchronize", "ldsp_last_error_string", "ldsp_ctx_set_option", "ldsp_ctx_enable_timing",
     "ldsp_ctx_last_kernel_ms", "ldsp_icpc_run", "ldsp_icpc_pz_trap_run", "ldsp_sipm_run",
     "ldsp_rdfilt_invcr", "ldsp_rdfilt_integrator", "ldsp_rdfilt_trap", "ldsp_rdfilt_fir",

@@ -357,6 +357,17 @@ def reference_test_icpc_config() -> DSPConfig:
     })
 
 
+def plumbing_icpc_config_4096() -> DSPConfig:
+    """BASELINE config 1 (1 k traces x 4096 samples): the default windows reach 110 us, so a
+    4096-sample trace must be sampled at 32 ns.  At 32 ns the fixed SG(60 ns) and the
+    100 ns estimator window are 3 points, which cannot carry a cubic: this plumbing config lowers
+    sg_flt_degree and int_interpolation_order to 2 (the reference would throw otherwise)."""
+    cfg = reference_test_icpc_config()
+    cfg.sg_flt_degree = 2
+    cfg.kwargs_pars = PropDict(dict(cfg.kwargs_pars, int_interpolation_order=2))
+    return cfg
+
+
 def reference_test_sipm_config() -> PropDict:
     return PropDict({
         "t0_hpge_window": [47.0 * us, 53.0 * us], "sg_flt_degree": 3,

@@ -32,17 +32,23 @@ struct WinDev {
 // derived in double on the host.
 struct CuspZacDev {
   int32_t Lf, lt, flat, f1, ltp;  // taps, rise length, flat, first fall tap, fall length Lf-f1
-  float q;                         // exp(-1/sigma)
+  int32_t is_zac;
+  float q_hi, q_lo;                // q = exp(-1/sigma) as a two-float sum (q_hi alone drifts by
+                                   // (1+3e-8)^1000 over a flank)
+  float a32_hi, a32_lo;            // q^32, the decay across one 32-sample thread chunk
+  float qpow[33];                  // q^e, e = 0..32
   float eps;                       // 1 - exp(-1/tau)
   float sc_half_den;               // beta/Lf / (2 sinh(lt/sigma))
   float sc;                        // beta/Lf
   float q_lt, q_mlt1;              // q^lt, q^-(lt-1)
   float q_ltp1, q_mltp;            // q^(ltp-1), q^-ltp
-  float w_last;                    // shape[Lf-1] * sc (tap that multiplies y[k] directly)
-  float rho_sc;                    // ZAC: -acusp/apar * beta/Lf (multiplies the parabola part)
-  float par_last;                  // ZAC: par[Lf-1]
-  int32_t is_zac;
-  int32_t _pad;
+  float q1, q2;                    // q, q^2
+  float w_last;                    // sc * shape[Lf-1] (the tap that multiplies y[k] directly)
+  float rho_sc;                    // ZAC: sc * acusp/apar (multiplies the parabola part)
+  // ZAC parabola part = double prefix sum of u[n] = sum_e zu_coef[e] * Dp[n - zu_shift[e]]
+  int32_t zu_n;
+  int32_t zu_shift[12];
+  float zu_coef[12];
 };
 
 struct IcpcDev {
@@ -67,6 +73,7 @@ struct IcpcDev {
   CuspZacDev cusp, zac;
   int32_t cz_shared;  // cusp and zac share sigma/flat/length/tau: one set of recursions
   int32_t cusp_mode;  // 0 = direct-form FIR (comparator), 1 = closed-form recursions
+  int32_t dbg_stop;   // profiling aid: return after phase N (0 = run everything)
   const float* h_cusp; // device, true-convolution taps (mode 0)
   const float* h_zac;
 };

@@ -282,6 +282,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOu
   }
   float* yr = xr;  // from here on the registers hold the PZ-corrected trace y
 
+  if (P.dbg_stop == 1) return;
   // ------------------------------------------------- phase 2: prefix sum of y
   WinAcc pz = {0, 0, 0};
   {
@@ -320,6 +321,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOu
   // y[32t-1], needed again in phase 5 after B0 has been recycled
   const float yprev = (i0t > 0) ? S.B0[sw(i0t - 1)] : 0.f;
 
+  if (P.dbg_stop == 2) return;
   // ------------------------------------------------ phase 3: lane-strided sweep
   const float thr_tx[5] = {e_max * 0.1f, e_max * 0.5f, e_max * 0.8f, e_max * 0.9f, e_max * 0.99f};
   float mx_f[3] = {-INFINITY, -INFINITY, -INFINITY}, mn_f[3] = {INFINITY, INFINITY, INFINITY};
@@ -358,6 +360,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOu
     mx_opt = block_reduce_vimax(mx_opt, S.red);
   }
 
+  if (P.dbg_stop == 3) return;
   // Intersect scans on the bit-masks (thread w <-> word w)
   int cnt7[7], first7[7];
   {
@@ -418,6 +421,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOu
     }
   }
 
+  if (P.dbg_stop == 4) return;
   // ------------------------------------------------ phase 3c: signal estimators
   // e_trap = SignalEstimator(trap_opt output, t50 + rt + ft/2)     dsp_icpc.jl:163
   float e_trap;
@@ -441,6 +445,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOu
     lq = (b2 - b1) - (b1 - b0);
   }
 
+  if (P.dbg_stop == 5) return;
   // ----------------------------------- phase 4: SG derivatives, current maxima
   // lane-strided: g[k] = sum_i c[i] y[k+i] from LDS (valid mode, trailing time axis).
   // The SG(sg_wl) output is needed in full (pile-up scan, t50_current) and is
@@ -556,8 +561,54 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOu
     }
   }
 
+  if (P.dbg_stop == 6) return;
   // ------------------------------------------------------ phase 5: CUSP / ZAC
   float e_cz[2] = {NAN, NAN}, mx_cz[2] = {NAN, NAN}, tmx_cz[2] = {NAN, NAN};
+  // extremestats + SignalEstimator on filter outputs held lane-strided in registers
+  // (acc[m] = out[tid + NT*m]); f = 0 CUSP, 1 ZAC.          dsp_icpc.jl:170-171,177-178
+  auto finish = [&](int f, int Lf, const float (&acc)[SPT]) {
+    const int nout = L - Lf + 1;
+    ValIdx best = {-INFINITY, 0x7fffffff};
+    Pos p = pos_add(ptx[1], f ? P.zac_pickoff : P.cusp_pickoff);
+    p.ip -= (Lf - 1);
+    float esum = NAN;
+    if (nout >= P.sig_est.npts) {
+      if (p.ip < 0) { p.ip = 0; p.fp = 0.f; }
+      if (p.ip >= nout - 1) { p.ip = nout - 1; p.fp = 0.f; }
+      int i0 = p.ip + (int)ceilf(p.fp - 0.5f * (float)P.sig_est.npts);
+      i0 = max(0, min(i0, nout - P.sig_est.npts));
+      float u = ((float)(p.ip - i0) + p.fp - P.sig_est.c) * P.sig_est.s_inv;
+      float part = 0.f;
+#pragma unroll
+      for (int m = 0; m < SPT; ++m) {
+        int k = tid + NT * m;
+        if (k < nout) {
+          if (acc[m] > best.v) { best.v = acc[m]; best.i = k; }
+          int l = k - i0;
+          if (l >= 0 && l < P.sig_est.npts) {
+            const float* b = &P.sig_est.B[l * (LDSP_MAX_EST_DEG + 1)];
+            float wgt = b[P.sig_est.deg];
+            for (int jj = P.sig_est.deg - 1; jj >= 0; --jj) wgt = fmaf(wgt, u, b[jj]);
+            part = fmaf(wgt, acc[m], part);
+          }
+        }
+      }
+      float pv[1] = {part};
+      block_reduce<1>(pv, reinterpret_cast<float*>(S.red), OpSum());
+      esum = pv[0];
+    } else {
+#pragma unroll
+      for (int m = 0; m < SPT; ++m) {
+        int k = tid + NT * m;
+        if (k < nout && acc[m] > best.v) { best.v = acc[m]; best.i = k; }
+      }
+    }
+    best = block_reduce_vimax(best, S.red);
+    e_cz[f] = esum;
+    mx_cz[f] = best.v;
+    tmx_cz[f] = P.t_first + P.dt * (float)(best.i + Lf - 1);
+  };
+
   if (P.cusp_mode == 0) {
     // direct-form FIR comparator: out[k] = sum_j h[j] y[k+Lf-1-j]
     for (int f = 0; f < 2; ++f) {
@@ -576,46 +627,184 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOu
           if (k < nout) acc[m] = fmaf(hj, S.B0[sw(k + sh)], acc[m]);
         }
       }
-      // extremestats + estimator on the register-resident outputs
-      ValIdx best = {-INFINITY, 0x7fffffff};
-      Pos p = pos_add(ptx[1], f ? P.zac_pickoff : P.cusp_pickoff);
-      p.ip -= (Lf - 1);
-      float esum = NAN;
-      if (nout >= P.sig_est.npts) {
-        if (p.ip < 0) { p.ip = 0; p.fp = 0.f; }
-        if (p.ip >= nout - 1) { p.ip = nout - 1; p.fp = 0.f; }
-        int i0 = p.ip + (int)ceilf(p.fp - 0.5f * (float)P.sig_est.npts);
-        i0 = max(0, min(i0, nout - P.sig_est.npts));
-        float u = ((float)(p.ip - i0) + p.fp - P.sig_est.c) * P.sig_est.s_inv;
-        float part = 0.f;
+      finish(f, Lf, acc);
+    }
+  } else {
+    // Closed form.  With d[i] = y[i] - a*y[i-1] (a = exp(-1/tau)):
+    //   out[k] = sc * ( sum_{j<=Lf-2} w[j] d[n-j] + w[Lf-1] y[k] ),  n = k+Lf-1
+    // and w = sinh flanks + flat top (+ parabolas for ZAC) splits into
+    //   G[i] = sum_m q^m d[i-m]   causal one-pole      (thread-blocked scan, forward)
+    //   A[i] = sum_m q^m d[i+m]   anti-causal one-pole (thread-blocked scan, backward)
+    //   Dp[i] = sum_{m<=i} d[m] = y[i]-y[0]+eps*T[i]   (flat top; eps = 1-a)
+    //   PRF = double prefix sum of a sparse combination of Dp (ZAC parabolas, in f64)
+    // each read back lane-strided at a handful of fixed shifts.  B0/B1 are recycled.
+    const int npass = P.cz_shared ? 1 : 2;
+    for (int pass = 0; pass < npass; ++pass) {
+      const bool want_c = P.cz_shared || pass == 0;
+      const bool want_z = P.cz_shared || pass == 1;
+      const CuspZacDev& Z = (pass == 0) ? P.cusp : P.zac;  // geometry + exponentials of this pass
+      const CuspZacDev& ZZ = P.zac;                         // parabola constants
+      const int Lf = Z.Lf, nout = L - Lf + 1, lt = Z.lt, f1 = Z.f1, ltp = Z.ltp;
+      if (pass == 1) {  // restore y in B0 (recycled by pass 0)
+        __syncthreads();
 #pragma unroll
-        for (int m = 0; m < SPT; ++m) {
-          int k = tid + NT * m;
-          if (k < nout) {
-            if (acc[m] > best.v) { best.v = acc[m]; best.i = k; }
-            int l = k - i0;
-            if (l >= 0 && l < P.sig_est.npts) {
-              const float* b = &P.sig_est.B[l * (LDSP_MAX_EST_DEG + 1)];
-              float wgt = b[P.sig_est.deg];
-              for (int jj = P.sig_est.deg - 1; jj >= 0; --jj) wgt = fmaf(wgt, u, b[jj]);
-              part = fmaf(wgt, acc[m], part);
-            }
+        for (int c = 0; c < SPT / 4; ++c)
+          *reinterpret_cast<float4*>(&S.B0[sw(i0t + 4 * c)]) = make_float4(yr[4 * c], yr[4 * c + 1], yr[4 * c + 2], yr[4 * c + 3]);
+      }
+      // ---- step A0: Dp -> B1 (thread-blocked)
+      {
+        float run = 0.f;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) { loc[j] = run; run += yr[j]; }
+        const double t_off = block_exscan_f64((double)run, S.red, nullptr);  // barriers: B1 (g) reads done, B0 restored
+        const float y0 = S.B0[0];
+#pragma unroll
+        for (int c = 0; c < SPT / 4; ++c) {
+          float4 v;
+          float* pv = &v.x;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = 4 * c + e;
+            const float Ti = (float)(t_off + (double)loc[j]);
+            pv[e] = (yr[j] - y0) + Z.eps * Ti;
           }
-        }
-        float pv[1] = {part};
-        block_reduce<1>(pv, reinterpret_cast<float*>(S.red), OpSum());
-        esum = pv[0];
-      } else {
-#pragma unroll
-        for (int m = 0; m < SPT; ++m) {
-          int k = tid + NT * m;
-          if (k < nout && acc[m] > best.v) { best.v = acc[m]; best.i = k; }
+          *reinterpret_cast<float4*>(&S.B1[sw(i0t + 4 * c)]) = v;
         }
       }
-      best = block_reduce_vimax(best, S.red);
-      e_cz[f] = esum;
-      mx_cz[f] = best.v;
-      tmx_cz[f] = P.t_first + P.dt * (float)(best.i + Lf - 1);
+      __syncthreads();
+      // ---- step A1 (lane-strided): flat top + last tap; ZAC: u[n] -> B0 in place
+      float ac[SPT], dz[SPT];
+      {
+        const float dwl = want_c ? (ZZ.w_last - Z.w_last) : 0.f;  // shared pass: ZAC last tap relative to CUSP's
+        const float wl = want_c ? Z.w_last : ZZ.w_last;
+        for (int m = 0; m < SPT; ++m) {
+          const int k = tid + NT * m;
+          float a = 0.f, z = 0.f;
+          const float yk = S.B0[sw(k)];
+          if (k < nout) {
+            const int n = k + Lf - 1;
+            a = Z.sc * (S.B1[sw(n - lt)] - S.B1[sw(n - f1)]) + wl * yk;
+            z = dwl * yk;
+          }
+          ac[m] = a; dz[m] = z;
+          if (want_z) {
+            float u = 0.f;
+            for (int e = 0; e < ZZ.zu_n; ++e) {
+              const int i = k - ZZ.zu_shift[e];
+              if (i > 0 && k < L) u = fmaf(ZZ.zu_coef[e], S.B1[sw(i)], u);
+            }
+            S.B0[sw(k)] = u;  // same index this thread just read: in-place is race-free
+          }
+        }
+      }
+      if (want_z) {
+        // ---- step A2 (thread-blocked): PRF = cumsum(cumsum(u)) in f64, two sweeps
+        __syncthreads();
+        float ur[SPT];
+#pragma unroll
+        for (int c = 0; c < SPT / 4; ++c) {
+          float4 v = *reinterpret_cast<const float4*>(&S.B0[sw(i0t + 4 * c)]);
+          ur[4 * c] = v.x; ur[4 * c + 1] = v.y; ur[4 * c + 2] = v.z; ur[4 * c + 3] = v.w;
+        }
+        double c1 = 0, V = 0;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) { c1 += (double)ur[j]; V += c1; }
+        const double O1 = block_exscan_f64(c1, S.red, nullptr);
+        const double O2 = block_exscan_f64((double)SPT * O1 + V, S.red, nullptr);
+        c1 = O1;
+        double c2 = O2;
+        const double mrho = -(double)ZZ.rho_sc;
+#pragma unroll
+        for (int c = 0; c < SPT / 4; ++c) {
+          float4 v;
+          float* pv = &v.x;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            c1 += (double)ur[4 * c + e];
+            c2 += c1;
+            pv[e] = (float)(mrho * c2);
+          }
+          *reinterpret_cast<float4*>(&S.B0[sw(i0t + 4 * c)]) = v;
+        }
+        __syncthreads();
+        for (int m = 0; m < SPT; ++m) {
+          const int k = tid + NT * m;
+          if (k < nout) dz[m] += S.B0[sw(k + Lf - 1)];
+        }
+      }
+      // ---- step B: causal one-pole G -> B1, rise(-) and fall(+) exponentials
+      // d[i] = (y[i]-y[i-1]) + eps*y[i-1] for 1 <= i < L, else 0
+      float dr[SPT];
+#pragma unroll
+      for (int j = 0; j < SPT; ++j) {
+        const float yp = (j == 0) ? yprev : yr[(j - 1) & (SPT - 1)];
+        const int i = i0t + j;
+        dr[j] = (i >= 1 && i < L) ? (yr[j] - yp) + Z.eps * yp : 0.f;
+      }
+      {
+        float g = 0.f;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+          const float t = fmaf(Z.q_hi, g, dr[j]);
+          g = fmaf(Z.q_lo, g, t);
+          loc[j] = g;
+        }
+        const float carry = block_exscan_affine(Z.a32_hi, g, reinterpret_cast<float*>(S.red));  // barriers: A1 reads of B1 done
+#pragma unroll
+        for (int c = 0; c < SPT / 4; ++c) {
+          float4 v;
+          float* pv = &v.x;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pv[e] = fmaf(Z.qpow[4 * c + e + 1], carry, loc[4 * c + e]);
+          *reinterpret_cast<float4*>(&S.B1[sw(i0t + 4 * c)]) = v;
+        }
+      }
+      __syncthreads();
+      for (int m = 0; m < SPT; ++m) {
+        const int k = tid + NT * m;
+        if (k < nout) {
+          const int n = k + Lf - 1;
+          const float pm = S.B1[sw(n)] - Z.q_lt * S.B1[sw(n - lt)];
+          const float fp = Z.q_mltp * (S.B1[sw(k + ltp - 1)] - Z.q_ltp1 * S.B1[sw(k)]);
+          ac[m] = fmaf(Z.sc_half_den, fp - pm, ac[m]);
+        }
+      }
+      // ---- step C: anti-causal one-pole A -> B1, rise(+) and fall(-) exponentials
+      {
+        float a = 0.f;
+#pragma unroll
+        for (int j = SPT - 1; j >= 0; --j) {
+          const float t = fmaf(Z.q_hi, a, dr[j]);
+          a = fmaf(Z.q_lo, a, t);
+          loc[j] = a;
+        }
+        const float carry = block_exscan_affine_rev(Z.a32_hi, a, reinterpret_cast<float*>(S.red));  // barriers: G reads done
+#pragma unroll
+        for (int c = 0; c < SPT / 4; ++c) {
+          float4 v;
+          float* pv = &v.x;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pv[e] = fmaf(Z.qpow[SPT - (4 * c + e)], carry, loc[4 * c + e]);
+          *reinterpret_cast<float4*>(&S.B1[sw(i0t + 4 * c)]) = v;
+        }
+        if (tid == 0) S.B1[sw(Lp)] = 0.f;  // A[L] when L == Lp
+      }
+      __syncthreads();
+      for (int m = 0; m < SPT; ++m) {
+        const int k = tid + NT * m;
+        if (k < nout) {
+          const int n = k + Lf - 1;
+          const float pp = Z.q_mlt1 * S.B1[sw(n - lt + 1)] - Z.q1 * S.B1[sw(n + 1)];
+          const float fm = Z.q2 * (S.B1[sw(k + 1)] - Z.q_ltp1 * S.B1[sw(k + ltp)]);
+          ac[m] = fmaf(Z.sc_half_den, pp - fm, ac[m]);
+        }
+      }
+      if (want_c) finish(0, Lf, ac);
+      if (want_z) {
+#pragma unroll
+        for (int m = 0; m < SPT; ++m) dz[m] += ac[m];
+        finish(1, Lf, dz);
+      }
     }
   }
 

@@ -50,6 +50,7 @@ struct ldsp_ctx {
   float* d_hc = nullptr;
   float* d_hz = nullptr;
   int cusp_direct = 0;
+  int dbg_stop = 0;
   // timing
   int timing = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -95,18 +96,24 @@ int ldsp_ctx_create(int device, ldsp_ctx** out) {
 
 int ldsp_ctx_destroy(ldsp_ctx* c) {
   if (!c) return LDSP_OK;
-  hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
-  hipFree(c->d_icpc); hipFree(c->d_hc); hipFree(c->d_hz);
-  hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
-  hipStreamDestroy(c->own_stream);
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz);
+  (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->own_stream);
   delete c;
   return LDSP_OK;
 }
 
 int ldsp_ctx_set_stream(ldsp_ctx* c, void* s) {
   if (!c) return fail(LDSP_ERR_INVALID_ARG, "ctx is NULL");
-  c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+  c->stream = reinterpret_cast<hipStream_t>(s);
+  return LDSP_OK;
+}
+
+int ldsp_ctx_use_own_stream(ldsp_ctx* c) {
+  if (!c) return fail(LDSP_ERR_INVALID_ARG, "ctx is NULL");
+  c->stream = c->own_stream;
   return LDSP_OK;
 }
 
@@ -119,6 +126,7 @@ int ldsp_ctx_synchronize(ldsp_ctx* c) {
 int ldsp_ctx_set_option(ldsp_ctx* c, const char* key, int64_t value) {
   if (!c || !key) return fail(LDSP_ERR_INVALID_ARG, "ctx/key is NULL");
   if (!strcmp(key, "cusp_direct")) { c->cusp_direct = value != 0; return LDSP_OK; }
+  if (!strcmp(key, "dbg_stop")) { c->dbg_stop = (int)value; c->icpc_valid = false; return LDSP_OK; }
   return fail(LDSP_ERR_INVALID_ARG, "unknown option '%s'", key);
 }
 
@@ -197,12 +205,16 @@ static bool make_est(const ldsp_dni& e, EstDev& d) {
   return true;
 }
 
-static void make_cuspzac(const ldsp_cuspzac& p, bool zac, CuspZacDev& d) {
+static bool make_cuspzac(const ldsp_cuspzac& p, bool zac, CuspZacDev& d) {
   hm::CuspShape g = hm::cusp_geometry(p);
   memset(&d, 0, sizeof d);
   d.Lf = g.Lf; d.lt = g.lt; d.flat = g.flat; d.f1 = g.f1; d.ltp = g.ltp;
+  d.is_zac = zac;
   const double q = std::exp(-1.0 / p.sigma), sc = p.beta / (double)p.length;
-  d.q = (float)q;
+  d.q_hi = (float)q; d.q_lo = (float)(q - (double)d.q_hi);
+  const double a32 = std::exp(-32.0 / p.sigma);
+  d.a32_hi = (float)a32; d.a32_lo = (float)(a32 - (double)d.a32_hi);
+  for (int e = 0; e <= 32; ++e) d.qpow[e] = (float)std::exp(-(double)e / p.sigma);
   d.eps = (float)(-std::expm1(-1.0 / p.tau));
   d.sc = (float)sc;
   d.sc_half_den = (float)(sc * 0.5 / g.den);
@@ -210,15 +222,31 @@ static void make_cuspzac(const ldsp_cuspzac& p, bool zac, CuspZacDev& d) {
   d.q_mlt1 = (float)std::exp((double)(g.lt - 1) / p.sigma);
   d.q_ltp1 = (float)std::exp(-(double)(g.ltp - 1) / p.sigma);
   d.q_mltp = (float)std::exp((double)g.ltp / p.sigma);
+  d.q1 = (float)q; d.q2 = (float)(q * q);
   std::vector<double> cusp, par;
   hm::cusp_and_par(p, cusp, par);
   double apar = 0, acusp = 0;
   for (int j = 0; j < g.Lf; ++j) { apar += par[j]; acusp += cusp[j]; }
-  double rho = zac ? acusp / apar : 0.0;
+  const double rho = zac ? acusp / apar : 0.0;
   d.w_last = (float)(sc * (cusp[g.Lf - 1] - rho * par[g.Lf - 1]));
   d.rho_sc = (float)(rho * sc);
-  d.par_last = (float)par[g.Lf - 1];
-  d.is_zac = zac;
+  if (!zac) return true;
+  // Second difference of the parabola kernel restricted to taps 0..Lf-2 (the last
+  // tap multiplies y[k] directly): constant 2 on two ranges plus a few edge taps.
+  // u[n] = sum_j D2[j] d[n-j],  d[i] = Dp[i]-Dp[i-1]  =>  u[n] = sum_e coef_e Dp[n-shift_e].
+  std::vector<double> ext(g.Lf + 3, 0.0), D2(g.Lf + 3, 0.0);
+  for (int j = 0; j <= g.Lf - 2; ++j) ext[j] = par[j];
+  for (int j = 0; j < g.Lf + 2; ++j) D2[j] = ext[j] - (j >= 1 ? 2 * ext[j - 1] : 0.0) + (j >= 2 ? ext[j - 2] : 0.0);
+  // coefficient of Dp[n-s]: D2[s] - D2[s-1]
+  std::vector<std::pair<int, double>> terms;
+  for (int sft = 0; sft <= g.Lf + 2; ++sft) {
+    double c = (sft < g.Lf + 2 ? D2[sft] : 0.0) - (sft >= 1 ? D2[sft - 1] : 0.0);
+    if (std::fabs(c) > 1e-9) terms.push_back({sft, c});
+  }
+  if (terms.size() > 12) return false;
+  d.zu_n = (int)terms.size();
+  for (size_t e = 0; e < terms.size(); ++e) { d.zu_shift[e] = terms[e].first; d.zu_coef[e] = (float)terms[e].second; }
+  return true;
 }
 
 static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, IcpcDev& d, std::vector<float>& hc, std::vector<float>& hz) {
@@ -281,11 +309,10 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, IcpcDev& d
   if (!hm::cusp_shape_ok(p.cusp) || !hm::cusp_shape_ok(p.zac) || p.cusp.length > L || p.zac.length > L ||
       p.cusp.length > LDSP_MAX_FIR_TAPS || p.zac.length > LDSP_MAX_FIR_TAPS)
     return fail(LDSP_ERR_WINDOW, "CUSP/ZAC filter does not fit the trace");
-  make_cuspzac(p.cusp, false, d.cusp);
-  make_cuspzac(p.zac, true, d.zac);
+  bool cz_ok = make_cuspzac(p.cusp, false, d.cusp) && make_cuspzac(p.zac, true, d.zac);
   d.cz_shared = p.cusp.sigma == p.zac.sigma && p.cusp.flat == p.zac.flat && p.cusp.length == p.zac.length &&
                 p.cusp.tau == p.zac.tau && p.cusp.beta == p.zac.beta;
-  d.cusp_mode = cusp_direct ? 0 : 1;
+  d.cusp_mode = (cusp_direct || !cz_ok) ? 0 : 1;  // unexpected kernel structure -> direct-form comparator
   std::vector<double> h;
   hm::cuspzac_taps(p.cusp, false, h);
   hc.assign(h.begin(), h.end());
@@ -301,6 +328,7 @@ static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p) {
   int rc = lower_icpc_dev(*p, c->cusp_direct, d, hc, hz);
   if (rc) return rc;
   d.h_cusp = c->d_hc; d.h_zac = c->d_hz;
+  d.dbg_stop = c->dbg_stop;
   c->icpc_host = d;
   HIP_TRY(hipMemcpyAsync(c->d_icpc, &c->icpc_host, sizeof(IcpcDev), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_hc, hc.data(), sizeof(float) * hc.size(), hipMemcpyHostToDevice, c->stream));

@@ -128,6 +128,26 @@ __device__ __forceinline__ float block_exscan_affine(float a, float b, float* sc
   return fmaf(ea, s, eb);
 }
 
+// Mirror image: maps composed from the LAST thread towards the first (anti-causal
+// recurrences); returns the state entering the thread's chunk from the right.
+__device__ __forceinline__ float block_exscan_affine_rev(float a, float b, float* scratch /*[2*MAX_WAVES]*/) {
+  const int nw = blockDim.x >> 6, w = wave_id(), l = lane_id();
+  float A = a, Bv = b;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float pa = __shfl_down(A, o, 64), pb = __shfl_down(Bv, o, 64);
+    if (l + o < 64) { Bv = fmaf(A, pb, Bv); A = A * pa; }
+  }
+  if (l == 0) { scratch[2 * w] = A; scratch[2 * w + 1] = Bv; }
+  __syncthreads();
+  float s = 0.f;
+  for (int i = nw - 1; i > w; --i) s = fmaf(scratch[2 * i], s, scratch[2 * i + 1]);
+  __syncthreads();
+  float ea = __shfl_down(A, 1, 64), eb = __shfl_down(Bv, 1, 64);
+  if (l == 63) { ea = 1.f; eb = 0.f; }
+  return fmaf(ea, s, eb);
+}
+
 // ---- bit-mask helpers ----------------------------------------------------------
 // A threshold decision per sample is kept as a bit array in LDS (bit b of word w
 // = sample 32w+b), written by wave ballots in the lane-strided view.

@@ -1,0 +1,46 @@
+"""Multi-GPU driver of the hot path: shard the waveform batch, gather the table.
+
+The path shards naturally: no statement of dsp_icpc / dsp_sipm
+combines data across traces.  One process per GPU; rank r owns the contiguous
+trace range `shard_range(n, world, r)`, runs the fused kernel on it, and the
+only collective is ONE gather of the [n_r, 48] float32 output shards to rank 0
+(`torch.distributed` backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
+the CPU tests).  No data-path collective.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, world: int, rank: int):
+    """Contiguous, balanced partition of range(n): first (n % world) ranks get one extra trace."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def gather_table(tab: torch.Tensor, n_total: int, dst: int = 0, group=None):
+    """Gather the per-rank [n_r, C] shards into the [n_total, C] table on `dst`
+    (row order = global trace index).  Returns the table on dst, None elsewhere.
+
+    Shards may differ by one row; they are padded to the largest shard so that a
+    single fixed-size gather moves everything (one collective, direct peer links)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return tab
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    C = tab.shape[1]
+    nmax = -(-n_total // world)
+    send = tab
+    if tab.shape[0] != nmax:
+        send = torch.zeros((nmax, C), dtype=tab.dtype, device=tab.device)
+        send[: tab.shape[0]] = tab
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, world, r)
+        parts.append(bufs[r][: hi - lo])
+    return torch.cat(parts, dim=0)

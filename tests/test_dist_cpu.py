@@ -1,0 +1,53 @@
+"""N > 1 path on CPU: world_size-2 gloo ranks shard a batch and gather the table."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from legenddsp_jl_amd import dist as ldist
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 1000, 1_000_003):
+        for w in (1, 2, 3, 8):
+            r = [ldist.shard_range(n, w, k) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = ldist.shard_range(n, world, rank)
+    # stand-in for the per-rank kernel output: row i of the table = f(global trace index)
+    idx = torch.arange(lo, hi, dtype=torch.float32)
+    tab = torch.stack([idx * (c + 1) for c in range(48)], dim=1)
+    full = ldist.gather_table(tab, n, dst=0)
+    if rank == 0:
+        q.put(full.numpy())
+    else:
+        assert full is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [10, 11])
+def test_gather_table_gloo(n):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    expect = np.stack([np.arange(n, dtype=np.float32) * (c + 1) for c in range(48)], axis=1)
+    np.testing.assert_array_equal(full, expect)

@@ -1,0 +1,15 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import legenddsp_jl_amd as ldsp
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+L = 8192
+p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, L, 0.0, 16.0)
+wf = ldsp.synth.hpge_batch(n, L, device="cuda")
+ctx = ldsp.default_context(); ctx.enable_timing(True)
+prev = 0
+for stop in (1, 2, 3, 4, 5, 6, 0):
+    ctx.set_option("dbg_stop", stop)
+    ldsp.icpc_run(wf, p, ctx); torch.cuda.synchronize()
+    ms = min((ldsp.icpc_run(wf, p, ctx), ctx.last_kernel_ms())[1] for _ in range(3))
+    print(f"stop after phase {stop}: {ms:.3f} ms (+{ms-prev:.3f})  {ms/n*1e3:.3f} us/wf"); prev = ms
