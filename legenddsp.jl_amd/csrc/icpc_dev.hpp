@@ -33,10 +33,10 @@ struct WinDev {
 struct CuspZacDev {
   int32_t Lf, lt, flat, f1, ltp;  // taps, rise length, flat, first fall tap, fall length Lf-f1
   int32_t is_zac;
-  float q_hi, q_lo;                // q = exp(-1/sigma) as a two-float sum (q_hi alone drifts by
-                                   // (1+3e-8)^1000 over a flank)
-  float a32_hi, a32_lo;            // q^32, the decay across one 32-sample thread chunk
-  float qpow[33];                  // q^e, e = 0..32
+  // q = exp(-1/sigma).  Every decay factor a kernel multiplies by is an exactly
+  // rounded power from these tables (a float q re-multiplied 1000x drifts by 3e-5):
+  float qp1[5];                    // q^e,    e = 0..4  (inside a 4-sample chunk)
+  float qp4[65];                   // q^(4j), j = 0..64 (across the lanes of a wave; qp4[64] = one wave-row)
   float eps;                       // 1 - exp(-1/tau)
   float sc_half_den;               // beta/Lf / (2 sinh(lt/sigma))
   float sc;                        // beta/Lf
@@ -52,7 +52,7 @@ struct CuspZacDev {
 };
 
 struct IcpcDev {
-  int32_t L, NT;
+  int32_t L, NT, R;   // trace length; threads and float4 rows per thread of the launch
   float t_first, dt, unit_per_us, inv_unit_per_us;
   float sat_low, sat_high;
   WinDev bl, tail, sgbl;

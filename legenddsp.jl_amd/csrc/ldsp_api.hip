@@ -14,7 +14,8 @@
 #include "icpc_dev.hpp"
 
 namespace ldsp {
-hipError_t launch_icpc(const float* wf, int64_t n, int NT, const IcpcDev* dP, const IcpcOutDev& out, hipStream_t st);
+hipError_t launch_icpc(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
+                       bool direct, bool cz_shared, int stop_after_main, hipStream_t st);
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 size_t icpc_smem_bytes(int NT);
 }  // namespace ldsp
@@ -49,6 +50,8 @@ struct ldsp_ctx {
   IcpcDev* d_icpc = nullptr;
   float* d_hc = nullptr;
   float* d_hz = nullptr;
+  float* d_aux = nullptr;   // [aux_cap][4] kernel 1 -> kernel 2 hand-over (blmean, t50 position)
+  int64_t aux_cap = 0;
   int cusp_direct = 0;
   int dbg_stop = 0;
   // timing
@@ -98,7 +101,7 @@ int ldsp_ctx_destroy(ldsp_ctx* c) {
   if (!c) return LDSP_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz);
+  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_aux);
   (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -211,10 +214,8 @@ static bool make_cuspzac(const ldsp_cuspzac& p, bool zac, CuspZacDev& d) {
   d.Lf = g.Lf; d.lt = g.lt; d.flat = g.flat; d.f1 = g.f1; d.ltp = g.ltp;
   d.is_zac = zac;
   const double q = std::exp(-1.0 / p.sigma), sc = p.beta / (double)p.length;
-  d.q_hi = (float)q; d.q_lo = (float)(q - (double)d.q_hi);
-  const double a32 = std::exp(-32.0 / p.sigma);
-  d.a32_hi = (float)a32; d.a32_lo = (float)(a32 - (double)d.a32_hi);
-  for (int e = 0; e <= 32; ++e) d.qpow[e] = (float)std::exp(-(double)e / p.sigma);
+  for (int e = 0; e <= 4; ++e) d.qp1[e] = (float)std::exp(-(double)e / p.sigma);
+  for (int j = 0; j <= 64; ++j) d.qp4[j] = (float)std::exp(-4.0 * j / p.sigma);
   d.eps = (float)(-std::expm1(-1.0 / p.tau));
   d.sc = (float)sc;
   d.sc_half_den = (float)(sc * 0.5 / g.den);
@@ -255,7 +256,13 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, IcpcDev& d
   if (L < 64 || L > LDSP_MAX_L) return fail(LDSP_ERR_UNSUPPORTED, "trace length %d outside [64, %d]", L, LDSP_MAX_L);
   if (!(p.dt > 0) || !(p.unit_per_us > 0)) return fail(LDSP_ERR_INVALID_ARG, "dt and unit_per_us must be positive");
   d.L = L;
-  d.NT = round_up((L + SPT_HOST - 1) / SPT_HOST, 64);
+  // launch geometry: NT threads x R float4 rows per thread, NT*4*R >= L
+  if (L <= 1024) { d.NT = 64; d.R = 4; }
+  else if (L <= 2048) { d.NT = 128; d.R = 4; }
+  else if (L <= 4096) { d.NT = 256; d.R = 4; }
+  else if (L <= 8192) { d.NT = 512; d.R = 4; }
+  else if (L <= 16384) { d.NT = 1024; d.R = 4; }
+  else return fail(LDSP_ERR_UNSUPPORTED, "dsp_icpc kernel keeps the trace in LDS: L <= 16384 (got %d)", L);
   d.t_first = (float)p.t_first; d.dt = (float)p.dt;
   d.unit_per_us = (float)p.unit_per_us; d.inv_unit_per_us = (float)(1.0 / p.unit_per_us);
   d.sat_low = (float)p.sat_low; d.sat_high = (float)p.sat_high;
@@ -352,9 +359,16 @@ int ldsp_icpc_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_param
   static_assert(sizeof(ldsp_icpc_out) == sizeof(void*) * LDSP_ICPC_NCOLS + sizeof(int64_t), "ldsp_icpc_out layout");
   memcpy(od.col, out, sizeof(void*) * LDSP_ICPC_NCOLS);
   od.stride = out->stride > 0 ? out->stride : 1;
-  if (icpc_smem_bytes(c->icpc_host.NT) > 160 * 1024) return fail(LDSP_ERR_UNSUPPORTED, "trace too long for the LDS-resident kernel");
+  if (n > c->aux_cap) {  // grow-only workspace; steady-state calls do not allocate
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_aux);
+    c->d_aux = nullptr; c->aux_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_aux, sizeof(float) * 4 * (size_t)n));
+    c->aux_cap = n;
+  }
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->d_icpc, od, c->stream));
+  HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->d_icpc, c->d_aux, od, c->icpc_host.cusp_mode == 0,
+                      c->icpc_host.cz_shared != 0, c->dbg_stop != 0, c->stream));
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; }
   return LDSP_OK;
 }

@@ -1,162 +1,124 @@
-// ldsp_device.hpp — device-side building blocks shared by the gfx950 kernels.
+// ldsp_device.hpp — device-side building blocks shared by the gfx950 trace kernels.
 //
-// Data model inside a workgroup: ONE trace per workgroup, NT = ceil(L/32)
-// threads (rounded to whole 64-lane waves).  Two register/LDS views of a trace:
-//   * thread-blocked: thread t owns samples 32t..32t+31 (serial recursions,
-//     prefix scans, bit-packing);
-//   * lane-strided:   thread t visits samples t, t+NT, t+2NT, ... (shifted
-//     reads for trapezoid/FIR windows: consecutive lanes -> consecutive banks).
-// LDS arrays use a 16-byte-chunk XOR swizzle so that thread-blocked
-// ds_read/write_b128 (row stride 128 B) are conflict-free while lane-strided
-// b32 accesses stay at most 2-way conflicted when a wave straddles two rows.
+// One trace per workgroup of NT threads.  Two views of a trace:
+//   * S4 ("striped by 4"): thread t holds, for each row r < R, the four
+//     consecutive samples 4*(t + NT*r) .. +3 — exactly what a coalesced
+//     global_load_dwordx4 delivers, and what a conflict-free ds_write_b128 into a
+//     LINEAR LDS array wants.  Prefix sums and one-pole recursions run in this
+//     view: 4-sample serial part, DPP scan across the 64 lanes of a wave, then
+//     one [R][NW] table of wave-row partials in LDS.
+//   * LS ("lane strided"): thread t visits samples t, t+NT, t+2NT, ...  Every
+//     shifted read T[k+s] of a trapezoid / FIR window is then a ds_read_b32 at a
+//     per-shift base register plus an IMMEDIATE row offset (no address VALU) and
+//     consecutive lanes hit consecutive banks whatever the shift.
+// Threshold decisions live as bit arrays in LDS, filled by wave ballots in the LS
+// view; Intersect-style run scans work on those words.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "wave_prims.hpp"
 
 namespace ldsp {
-
-constexpr int SPT = 32;        // samples per thread in the thread-blocked view
-constexpr int MAX_WAVES = 16;  // 1024 threads
-
-__device__ __forceinline__ int sw(int i) { return i ^ (((i >> 5) & 7) << 2); }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
-// ---- wave-level reductions (64 lanes) -------------------------------------
-template <typename T, typename Op>
-__device__ __forceinline__ T wave_reduce(T v, Op op) {
+// ---- S4 block scans -------------------------------------------------------------
+// Exclusive prefix (in double) of per-chunk totals, chunk order = t + NT*r.
+// tot[r]: total of this thread's 4-sample chunk in row r.  off[r]: sum of all
+// chunks before it.  part: LDS scratch [R*NW] doubles (caller alternates buffers).
+template <int NT, int R, typename T>
+__device__ __forceinline__ void s4_exscan_sum(const T (&tot)[R], double (&off)[R], double* part, double* total) {
+  constexpr int NW = NT / 64;
+  const int w = wave_id(), l = lane_id();
+  double inc[R];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o, 64));
-  return v;
-}
-struct OpSum { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
-struct OpMax { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a > b ? a : b; } };
-struct OpMin { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a < b ? a : b; } };
-
-// (value, index) pair; max by value, ties -> smaller index (findmax: first occurrence)
-struct ValIdx { float v; int i; };
-__device__ __forceinline__ ValIdx vi_max(ValIdx a, ValIdx b) {
-  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
-}
-__device__ __forceinline__ ValIdx wave_reduce_vimax(ValIdx x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    ValIdx y; y.v = __shfl_xor(x.v, o, 64); y.i = __shfl_xor(x.i, o, 64);
-    x = vi_max(x, y);
+  for (int r = 0; r < R; ++r) {
+    if constexpr (sizeof(T) == 8) inc[r] = wave_incl_scan_sum_f64((double)tot[r]);
+    else inc[r] = (double)wave_incl_scan_sum((float)tot[r]);
   }
-  return x;
+  if (l == 63) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) part[r * NW + w] = inc[r];
+  }
+  __syncthreads();
+  double acc = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    for (int ww = 0; ww < NW; ++ww) {
+      if (ww == w) off[r] = acc + (inc[r] - (double)tot[r]);
+      acc += part[r * NW + ww];
+    }
+  }
+  if (total) *total = acc;
 }
 
-// ---- block-level helpers -----------------------------------------------------
-// All take a scratch area in LDS of at least MAX_WAVES*K elements of T and end
-// with every thread holding the result.  Two barriers each (publish, release).
-template <int K, typename T, typename Op>
-__device__ __forceinline__ void block_reduce(T (&v)[K], T* scratch, Op op) {
-  const int nw = blockDim.x >> 6, w = wave_id(), l = lane_id();
+// One-pole recursion s <- a*s + b over chunks (a = q^4 constant): state ENTERING
+// each of the thread's chunks, forward direction (state 0 before chunk 0).
+// b[r]: the chunk's own end state from zero input state.
+// qp4[j] = q^(4j), j = 0..64 (LDS or global table).
+template <int NT, int R>
+__device__ __forceinline__ void s4_exscan_affine_fwd(const float (&b)[R], float (&s_in)[R], const float* qp4, float* part) {
+  constexpr int NW = NT / 64;
+  const int w = wave_id(), l = lane_id();
+  const AffinePow P = {qp4[1], qp4[2], qp4[4], qp4[8]};
+  const float f15 = qp4[(l & 15) + 1], f31 = qp4[(l & 31) + 1], fl = qp4[l], aw = qp4[64];
+  float inc[R];
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = wave_reduce(v[k], op);
+  for (int r = 0; r < R; ++r) inc[r] = wave_incl_scan_affine(b[r], P, f15, f31);
+  if (l == 63) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) part[r * NW + w] = inc[r];
+  }
+  __syncthreads();
+  float s = 0.f;  // state entering wave-row (r, w)
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float sw_in = 0.f;
+    for (int ww = 0; ww < NW; ++ww) {
+      if (ww == w) sw_in = s;
+      s = fmaf(aw, s, part[r * NW + ww]);
+    }
+    float ex = dpp_f<0x138>(0.f, inc[r]);  // wave_shr:1 — inclusive value of lane l-1 (0 for lane 0)
+    s_in[r] = fmaf(fl, sw_in, ex);
+  }
+}
+// Anti-causal mirror: state entering each chunk from the RIGHT (state 0 after the last chunk).
+template <int NT, int R>
+__device__ __forceinline__ void s4_exscan_affine_bwd(const float (&b)[R], float (&s_in)[R], const float* qp4, float* part) {
+  constexpr int NW = NT / 64;
+  const int w = wave_id(), l = lane_id();
+  const float pw[6] = {qp4[1], qp4[2], qp4[4], qp4[8], qp4[16], qp4[32]};
+  const float fl = qp4[63 - l], aw = qp4[64];
+  float inc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) inc[r] = wave_incl_scan_affine_rev(b[r], pw);
   if (l == 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) scratch[w * K + k] = v[k];
+    for (int r = 0; r < R; ++r) part[r * NW + w] = inc[r];
   }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    T a = scratch[k];
-    for (int i = 1; i < nw; ++i) a = op(a, scratch[i * K + k]);
-    v[k] = a;
-  }
-  __syncthreads();
-}
-
-__device__ __forceinline__ ValIdx block_reduce_vimax(ValIdx x, void* scratch_) {
-  ValIdx* scratch = reinterpret_cast<ValIdx*>(scratch_);
-  const int nw = blockDim.x >> 6, w = wave_id(), l = lane_id();
-  x = wave_reduce_vimax(x);
-  if (l == 0) scratch[w] = x;
-  __syncthreads();
-  ValIdx a = scratch[0];
-  for (int i = 1; i < nw; ++i) a = vi_max(a, scratch[i]);
-  __syncthreads();
-  return a;
-}
-
-// Exclusive prefix sum over the block of one double per thread (thread order).
-// Returns the exclusive prefix; *total (optional) receives the block total.
-__device__ __forceinline__ double block_exscan_f64(double v, double* scratch, double* total) {
-  const int nw = blockDim.x >> 6, w = wave_id(), l = lane_id();
-  double inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    double t = __shfl_up(inc, o, 64);
-    if (l >= o) inc += t;
-  }
-  if (l == 63) scratch[w] = inc;
-  __syncthreads();
-  double base = 0, tot = 0;
-  for (int i = 0; i < nw; ++i) {
-    double s = scratch[i];
-    if (i < w) base += s;
-    tot += s;
-  }
-  __syncthreads();
-  if (total) *total = tot;
-  return base + inc - v;
-}
-
-// Scan of first-order recurrences s <- a*s + b composed in thread order:
-// each thread contributes the affine map (a, b) of its 32-sample chunk; returns
-// the state ENTERING the thread's chunk given state 0 before thread 0.
-// (forward direction; for the anti-causal filter the caller mirrors thread ids)
-__device__ __forceinline__ float block_exscan_affine(float a, float b, float* scratch /*[2*MAX_WAVES]*/) {
-  const int nw = blockDim.x >> 6, w = wave_id(), l = lane_id();
-  float A = a, Bv = b;  // inclusive composite: x -> A*x + Bv
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    float pa = __shfl_up(A, o, 64), pb = __shfl_up(Bv, o, 64);
-    if (l >= o) { Bv = fmaf(A, pb, Bv); A = A * pa; }
-  }
-  if (l == 63) { scratch[2 * w] = A; scratch[2 * w + 1] = Bv; }
-  __syncthreads();
-  float s = 0.f;  // state entering this wave
-  for (int i = 0; i < w && i < nw; ++i) s = fmaf(scratch[2 * i], s, scratch[2 * i + 1]);
-  __syncthreads();
-  // exclusive within the wave: composite of lanes < l applied to s
-  float ea = __shfl_up(A, 1, 64), eb = __shfl_up(Bv, 1, 64);
-  if (l == 0) { ea = 1.f; eb = 0.f; }
-  return fmaf(ea, s, eb);
-}
-
-// Mirror image: maps composed from the LAST thread towards the first (anti-causal
-// recurrences); returns the state entering the thread's chunk from the right.
-__device__ __forceinline__ float block_exscan_affine_rev(float a, float b, float* scratch /*[2*MAX_WAVES]*/) {
-  const int nw = blockDim.x >> 6, w = wave_id(), l = lane_id();
-  float A = a, Bv = b;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    float pa = __shfl_down(A, o, 64), pb = __shfl_down(Bv, o, 64);
-    if (l + o < 64) { Bv = fmaf(A, pb, Bv); A = A * pa; }
-  }
-  if (l == 0) { scratch[2 * w] = A; scratch[2 * w + 1] = Bv; }
   __syncthreads();
   float s = 0.f;
-  for (int i = nw - 1; i > w; --i) s = fmaf(scratch[2 * i], s, scratch[2 * i + 1]);
-  __syncthreads();
-  float ea = __shfl_down(A, 1, 64), eb = __shfl_down(Bv, 1, 64);
-  if (l == 63) { ea = 1.f; eb = 0.f; }
-  return fmaf(ea, s, eb);
+#pragma unroll
+  for (int r = R - 1; r >= 0; --r) {
+    float sw_in = 0.f;
+    for (int ww = NW - 1; ww >= 0; --ww) {
+      if (ww == w) sw_in = s;
+      s = fmaf(aw, s, part[r * NW + ww]);
+    }
+    float ex = __shfl_down(inc[r], 1, 64);
+    if (l == 63) ex = 0.f;
+    s_in[r] = fmaf(fl, sw_in, ex);
+  }
 }
 
 // ---- bit-mask helpers ----------------------------------------------------------
-// A threshold decision per sample is kept as a bit array in LDS (bit b of word w
-// = sample 32w+b), written by wave ballots in the lane-strided view.
 __device__ __forceinline__ void ballot_store(bool pred, uint32_t* bm, int word_base) {
   unsigned long long m = __ballot(pred);
   if (lane_id() == 0) { bm[word_base] = (uint32_t)m; bm[word_base + 1] = (uint32_t)(m >> 32); }
 }
 
-// all bits [s, s+len) set?  (bits beyond the array are stored as zero)
+// all bits [s, s+len) set?  (bits beyond the trace are stored as zero)
 __device__ __forceinline__ bool bits_all_set(const uint32_t* bm, int s, int len, int nwords) {
   int pos = s, rem = len;
   while (rem > 0) {
@@ -170,11 +132,10 @@ __device__ __forceinline__ bool bits_all_set(const uint32_t* bm, int s, int len,
   return true;
 }
 
-// Intersect(min_n) on a bit array: counts runs of set bits that do not start at
-// sample 0 and are at least min_n long; *first = start of the first such run.
-// Word `w` is handled by thread w (call with w < nwords, others pass cnt=0).
-__device__ __forceinline__ void intersect_word(const uint32_t* bm, int w, int nwords, int min_n,
-                                               int* cnt, int* first) {
+// Intersect(min_n) on a bit array (RadiationDetectorDSP `_find_intersect_impl`, the
+// scan of reference src/intersect_maximum.jl:41-56): counts runs of set bits that do
+// not start at sample 0 and are at least min_n long; *first = start of the first one.
+__device__ __forceinline__ void intersect_word(const uint32_t* bm, int w, int nwords, int min_n, int* cnt, int* first) {
   uint32_t h = bm[w];
   uint32_t prev = (w == 0) ? 1u : (bm[w - 1] >> 31);  // sample -1 counts as "high": initial run excluded
   uint32_t starts = h & ~((h << 1) | prev);
@@ -183,26 +144,19 @@ __device__ __forceinline__ void intersect_word(const uint32_t* bm, int w, int nw
     int b = __ffs(starts) - 1;
     starts &= starts - 1;
     int s = 32 * w + b;
-    if (min_n <= 1 || bits_all_set(bm, s + 1, min_n - 1, nwords)) {
-      ++c;
-      f = min(f, s);
-    }
+    if (min_n <= 1 || bits_all_set(bm, s + 1, min_n - 1, nwords)) { ++c; f = min(f, s); }
   }
   *cnt = c; *first = f;
 }
-
-// The same scan on the REVERSED trace (get_intracePileUp, src/dsp_routines.jl:79):
-// runs that do not touch the last sample (n-1), at least min_n long, counted;
-// *last_end = largest end index of such a run (or -1).
-__device__ __forceinline__ void intersect_word_rev(const uint32_t* bm, int w, int nwords, int n, int min_n,
-                                                   int* cnt, int* last_end) {
+// The same scan on the REVERSED trace (get_intracePileUp, reference src/dsp_routines.jl:79):
+// runs that do not touch the last sample n-1, at least min_n long; *last_end = largest end index.
+__device__ __forceinline__ void intersect_word_rev(const uint32_t* bm, int w, int nwords, int n, int min_n, int* cnt, int* last_end) {
   uint32_t h = bm[w];
   uint32_t nextbit;
-  // bit of sample 32w+32; the sample just past the end (index n) counts as "high"
-  if (32 * w + 32 == n) nextbit = 1u;
+  if (32 * w + 32 == n) nextbit = 1u;  // the sample just past the end counts as "high"
   else nextbit = (w + 1 < nwords) ? (bm[w + 1] & 1u) : 0u;
   uint32_t hn = (h >> 1) | (nextbit << 31);
-  if ((n >> 5) == w && (n & 31) != 0) hn |= 1u << ((n & 31) - 1);  // sample n inside this word
+  if ((n >> 5) == w && (n & 31) != 0) hn |= 1u << ((n & 31) - 1);
   uint32_t ends = h & ~hn;
   int c = 0, e_best = -1;
   while (ends) {
@@ -211,10 +165,7 @@ __device__ __forceinline__ void intersect_word_rev(const uint32_t* bm, int w, in
     int e = 32 * w + b;
     if (e >= n) continue;
     int s = e - min_n + 1;
-    if (s >= 0 && (min_n <= 1 || bits_all_set(bm, s, min_n - 1, nwords))) {
-      ++c;
-      e_best = max(e_best, e);
-    }
+    if (s >= 0 && (min_n <= 1 || bits_all_set(bm, s, min_n - 1, nwords))) { ++c; e_best = max(e_best, e); }
   }
   *cnt = c; *last_end = e_best;
 }
@@ -223,6 +174,33 @@ __device__ __forceinline__ void intersect_word_rev(const uint32_t* bm, int w, in
 __device__ __forceinline__ float extrema3points(float y1, float y2, float y3) {
   float a = y3 - 4.f * y2 + 3.f * y1;
   return y1 - a * a / (8.f * (y3 - 2.f * y2 + y1));
+}
+
+// (value, index) packed so that an unsigned 64-bit max picks the largest value and,
+// among equal values, the SMALLEST index (findmax: first occurrence).
+// order-preserving map float <-> uint32 (a < b  <=>  ford(a) < ford(b)); lets float
+// max/min reductions run on the LDS integer atomics (ds_max_u32 / ds_min_u32)
+__device__ __forceinline__ uint32_t ford(float v) {
+  uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ford_inv(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ unsigned long long pack_vi(float v, int i) {
+  return ((unsigned long long)ford(v) << 32) | (uint32_t)(0x7fffffff - i);
+}
+__device__ __forceinline__ void unpack_vi(unsigned long long k, float* v, int* i) {
+  *v = ford_inv((uint32_t)(k >> 32));
+  *i = 0x7fffffff - (int)(uint32_t)(k & 0xffffffffu);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long t = __shfl_xor(k, o, 64);
+    k = t > k ? t : k;
+  }
+  return k;
 }
 
 }  // namespace ldsp

@@ -25,7 +25,7 @@ ATOL = {
     "tailmean": 0.05, "tailsigma": 5e-3, "tailslope": 2e-7, "tailoffset": 0.05,
     "tail_tau": 50.0, "tail_mean": 2e-6, "tail_sigma": 2e-6,
     "e_max": 2e-3, "e_min": 2e-3,
-    "e_10410": 0.05, "e_535": 0.05, "e_313": 0.05, "e_10410_inv": 0.05, "e_313_inv": 0.05,
+    "e_10410": 0.05, "e_535": 0.05, "e_313": 0.05, "e_10410_inv": 0.05, "e_313_inv": 0.1,
     "e_trap": 0.05, "e_cusp": 0.1, "e_zac": 0.1, "e_trap_max": 0.05, "e_cusp_max": 0.1, "e_zac_max": 0.1,
     "qdrift": 40.0, "lq": 40.0, "a_sg": 5e-3, "a_60": 5e-3, "a_100": 5e-3, "a_raw": 5e-3,
     "drift_time": 0.6, "inTrace_intersect": 0.6,

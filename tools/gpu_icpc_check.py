@@ -21,8 +21,8 @@ g = {k: v.cpu().numpy() for k, v in ldsp.table_columns(tab).items()}
 t = time.time(); o = orc.dsp_icpc(wf.cpu().numpy(), p, nthreads=16); print("oracle s", time.time() - t)
 lines, worst = parity.compare(g, o)
 print("\n".join(lines)); print("worst bad fraction", worst)
-for c in ["t0", "t50", "e_trap", "e_cusp", "e_zac", "qdrift", "lq", "a_sg", "inTrace_intersect", "t50_current", "tail_tau"]:
-    print(c, g[c][:3], o[c][:3])
+for c in ["e_10410_inv", "e_313_inv", "a_raw", "t0", "t50", "e_trap", "e_cusp", "e_zac", "qdrift", "lq", "a_sg", "inTrace_intersect", "t50_current", "tail_tau"]:
+    print(c, g[c][:4], o[c][:4]); bad = np.argmax(np.abs(g[c] - o[c])); print("   worst idx", bad, g[c][bad], o[c][bad])
 pz = ldsp.icpc_pz_trap_run(wf, p, ctx).cpu().numpy()
 o2 = orc.icpc_pz_trap(wf.cpu().numpy(), p)
 print("pz_trap blmean err", np.abs(pz[0] - o2["blmean"]).max(), "e_10410 rel err", (np.abs(pz[1] - o2["e_10410"]) / o2["e_10410"]).max())
