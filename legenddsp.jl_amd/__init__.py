@@ -11,6 +11,14 @@ from ._lib import Context, LdspError, build, default_context
 from .config import (DSPConfig, PropDict, ClosedInterval, StepRange, get_fltpars, lower_icpc, lower_sipm,
                      reference_test_icpc_config, reference_test_sipm_config, plumbing_icpc_config_4096,
                      ns, us, ms, WindowError)
-from .routines import ArrayOfRDWaveforms, Table, dsp_icpc, icpc_run, icpc_pz_trap_run, table_columns
+from .routines import (ArrayOfRDWaveforms, Table, dsp_icpc, dsp_sipm, icpc_run, icpc_pz_trap_run, sipm_run, table_columns,
+                       get_t0, get_threshold, get_qdrift, get_intracePileUp)
+from .filters import (SamplingInfo, smplinfo, fltinstance, rdfilt_, flt_output_length, flt_input_length,
+                      flt_output_time_axis, InvCRFilter, IntegratorFilter, TrapezoidalChargeFilter, CUSPChargeFilter,
+                      ZACChargeFilter, SavitzkyGolayFilter, DerivativeFilter, HaarAveragingFilter, MovingWindowFilter,
+                      MovingWindowMultiFilter, TruncateFilter, shift_waveform, multiply_waveform, reverse_waveform)
+from .extractors import (VectorOfVectors, signalstats, tailstats, extremestats, thresholdstats, thresholdstats_mad,
+                         saturation, get_wvf_maximum, Intersect, IntersectMaximum, MultiIntersect, PolynomialDNI,
+                         SignalEstimator)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

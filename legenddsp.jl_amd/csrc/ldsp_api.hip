@@ -12,6 +12,7 @@
 #include "../../include/ldsp.h"
 #include "host_math.hpp"
 #include "icpc_dev.hpp"
+#include "ldsp_ctx.hpp"
 
 namespace ldsp {
 hipError_t launch_icpc(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
@@ -23,7 +24,7 @@ size_t icpc_smem_bytes(int NT);
 using namespace ldsp;
 
 static thread_local std::string g_err;
-static int fail(int code, const char* fmt, ...) {
+int ldsp_fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -32,33 +33,17 @@ static int fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
-#define HIP_TRY(expr)                                                                        \
-  do {                                                                                       \
-    hipError_t _e = (expr);                                                                  \
-    if (_e != hipSuccess) return fail(LDSP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
-  } while (0)
+#define fail ldsp_fail
 
-struct ldsp_ctx {
-  int device = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  // dsp_icpc parameter staging
-  ldsp_icpc_params icpc_last{};
-  bool icpc_valid = false;
-  int icpc_mode_built = -1;
-  IcpcDev icpc_host{};
-  IcpcDev* d_icpc = nullptr;
-  float* d_hc = nullptr;
-  float* d_hz = nullptr;
-  float* d_aux = nullptr;   // [aux_cap][4] kernel 1 -> kernel 2 hand-over (blmean, t50 position)
-  int64_t aux_cap = 0;
-  int cusp_direct = 0;
-  int dbg_stop = 0;
-  // timing
-  int timing = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int n_launches = 0;
-};
+int ldsp_check_batch(ldsp_ctx* c, const void* x, int64_t n, int32_t L, const char* who) {
+  if (!c) return fail(LDSP_ERR_INVALID_ARG, "%s: ctx is NULL", who);
+  if (n < 0 || n > 0x7fffffffLL) return fail(LDSP_ERR_INVALID_ARG, "%s: n = %lld out of range", who, (long long)n);
+  if (L < 1 || L > LDSP_MAX_L) return fail(LDSP_ERR_UNSUPPORTED, "%s: trace length %d outside [1, %d]", who, L, LDSP_MAX_L);
+  if (n > 0 && !x) return fail(LDSP_ERR_INVALID_ARG, "%s: waveform pointer is NULL", who);
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail(LDSP_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+  return LDSP_OK;
+}
 
 extern "C" {
 
@@ -91,6 +76,7 @@ int ldsp_ctx_create(int device, ldsp_ctx** out) {
   HIP_TRY(hipMalloc(&c->d_icpc, sizeof(IcpcDev)));
   HIP_TRY(hipMalloc(&c->d_hc, sizeof(float) * LDSP_MAX_FIR_TAPS));
   HIP_TRY(hipMalloc(&c->d_hz, sizeof(float) * LDSP_MAX_FIR_TAPS));
+  HIP_TRY(hipMalloc(&c->d_coef, sizeof(float) * LDSP_MAX_FIR_TAPS));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   *out = c;
@@ -101,7 +87,7 @@ int ldsp_ctx_destroy(ldsp_ctx* c) {
   if (!c) return LDSP_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_aux);
+  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_aux); (void)hipFree(c->d_coef);
   (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->own_stream);
   delete c;

@@ -1,0 +1,41 @@
+// ldsp_ctx.hpp — internals shared by the translation units that implement the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include "../../include/ldsp.h"
+#include "icpc_dev.hpp"
+
+int ldsp_fail(int code, const char* fmt, ...);
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) return ldsp_fail(LDSP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+struct ldsp_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // dsp_icpc parameter staging
+  ldsp_icpc_params icpc_last{};
+  bool icpc_valid = false;
+  int icpc_mode_built = -1;
+  ldsp::IcpcDev icpc_host{};
+  ldsp::IcpcDev* d_icpc = nullptr;
+  float* d_hc = nullptr;
+  float* d_hz = nullptr;
+  float* d_aux = nullptr;   // [aux_cap][4] kernel 1 -> kernel 2 hand-over (blmean, t50 position)
+  int64_t aux_cap = 0;
+  float* d_coef = nullptr;  // [LDSP_MAX_FIR_TAPS] staging for functor coefficients / small tables
+  int cusp_direct = 0;
+  int dbg_stop = 0;
+  // timing
+  int timing = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int n_launches = 0;
+};
+
+// common argument checks of the per-trace entry points
+int ldsp_check_batch(ldsp_ctx* c, const void* x, int64_t n, int32_t L, const char* who);

@@ -1,0 +1,232 @@
+// sipm_kernel.hip — fused dsp_sipm for gfx950 (reference src/dsp_sipm.jl:47-158).
+//
+// One workgroup per trace; the trace is read from HBM once and every column is
+// produced from two LDS arrays:
+//   A: x  -> cumsum(I) -> P = InvCR(I) -> cumsum(P)
+//   B: g = SG'(x) -> I = cumsum(g) (-I serves the discharge scans) -> trapezoid output
+// MAD thresholds by radix select on monotone float keys, triggers by ballot bit-masks
+// (IntersectMaximum: ragged outputs as fixed-capacity slabs + counts).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "host_math.hpp"
+#include "ldsp_ctx.hpp"
+#include "trace_blocks.hpp"
+
+namespace ldsp {
+namespace sipm {
+
+using tb::Scratch;
+
+struct SipmDev {
+  int32_t L, np;
+  float t_first, dt, inv_upus;
+  int32_t trunc_from, trunc_until;
+  float sg_c[LDSP_MAX_SG_PTS];  // correlation taps
+  int32_t sg_mintot, sg_maxtot;
+  float sg_min_thr, sg_max_thr, sg_nsigma, sg_min_dc, sg_max_dc, sg_nsigma_dc;
+  float pz_c;
+  ldsp_trap trap;
+  int32_t trap_mintot, trap_maxtot;
+  float trap_min_thr, trap_max_thr, trap_nsigma, trap_min_dc, trap_max_dc, trap_nsigma_dc;
+};
+
+enum { S_t_max, S_t_min, S_t_max_lar, S_t_min_lar, S_e_max, S_e_min, S_e_max_lar, S_e_min_lar,
+       S_blmean, S_blsigma, S_blslope, S_bloffset, S_wfmean, S_wfsigma, S_wfslope, S_wfoffset,
+       S_threshold, S_threshold_DC, S_threshold_trap, S_threshold_DC_trap, S_NCOLS };
+
+struct SipmOutDev {
+  float* col[S_NCOLS];
+  ldsp_trig_out trig[4];  // SG, DC, trap, DC_trap
+};
+
+__device__ __forceinline__ int pad4(int n) { return ((n + 3) & ~3) + 64; }
+
+#include "intersect_maximum_block.inc"
+
+__global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, SipmDev P, SipmOutDev out) {
+  extern __shared__ __align__(16) unsigned char raw[];
+  const int L = P.L, tid = threadIdx.x, NT = blockDim.x;
+  float* A = reinterpret_cast<float*>(raw);
+  float* B = A + pad4(L);
+  uint32_t* bm = reinterpret_cast<uint32_t*>(B + pad4(L));
+  const int nwmax = ((L + 31) >> 5) + 2;
+  uintptr_t pp = reinterpret_cast<uintptr_t>(bm + nwmax);
+  pp = (pp + 15) & ~(uintptr_t)15;
+  Scratch& sc = *reinterpret_cast<Scratch*>(pp);
+  const size_t b = blockIdx.x;
+  auto put = [&](int c, float v) { if (tid == 0 && out.col[c]) out.col[c][b] = v; };
+
+  // shift_waveform(wvfs, 0.0)  (dsp_sipm.jl:88) — values unchanged
+  tb::load_trace(wf + b * (size_t)L, A, L);
+  for (int i = L + tid; i < pad4(L); i += NT) A[i] = 0.f;
+  __syncthreads();
+  {  // extremestats on the full trace and on TruncateFilter(t0_hpge_window)   :91-95
+    float vmin, vmax; int imin, imax;
+    tb::extreme_stats(A, 0, L - 1, sc, &vmin, &imin, &vmax, &imax);
+    put(S_e_min, vmin); put(S_e_max, vmax);
+    put(S_t_min, (P.t_first + P.dt * (float)imin) * P.inv_upus); put(S_t_max, (P.t_first + P.dt * (float)imax) * P.inv_upus);
+    tb::extreme_stats(A, P.trunc_from, P.trunc_until, sc, &vmin, &imin, &vmax, &imax);
+    put(S_e_min_lar, vmin); put(S_e_max_lar, vmax);
+    put(S_t_min_lar, (P.t_first + P.dt * (float)imin) * P.inv_upus); put(S_t_max_lar, (P.t_first + P.dt * (float)imax) * P.inv_upus);
+  }
+  // SavitzkyGolayFilter(wl, degree, 1): g -> B   :99-100   (valid mode, trailing time axis, A1)
+  const int np = P.np, ng = L - np + 1;
+  const float tg = P.t_first + P.dt * (float)(np - 1);
+  for (int k = tid; k < pad4(L); k += NT) {
+    float g = 0.f;
+    if (k < ng) for (int i = 0; i < np; ++i) g = fmaf(P.sg_c[i], A[k + i], g);
+    B[k] = g;
+  }
+  __syncthreads();
+  // SG triggers :103-105
+  const float thr_sg = tb::mad_threshold(B, ng, P.sg_min_thr, P.sg_max_thr, 1.f, sc);
+  put(S_threshold, thr_sg);
+  {
+    const float th = P.sg_nsigma * thr_sg;
+    tb::build_mask(B, ng, 1.f, th, bm);
+    __syncthreads();
+    if (tid == 0) sc.f[1] = 0.f;  // minimum.(inters.x; init = 0)
+    __syncthreads();
+    const ldsp_trig_out& o = out.trig[0];
+    const size_t off = b * LDSP_MAX_TRIG;
+    const int tot = intersect_maximum_block(B, ng, 1.f, th, P.sg_mintot, P.sg_maxtot, tg, P.dt, bm, sc, LDSP_MAX_TRIG,
+                                            o.x ? o.x + off : nullptr, o.x_high ? o.x_high + off : nullptr,
+                                            o.x_tot ? o.x_tot + off : nullptr, o.max ? o.max + off : nullptr, &sc.f[1]);
+    if (tid == 0 && o.count) o.count[b] = tot;
+  }
+  __syncthreads();
+  const float minx = fminf(sc.f[1], 0.f);
+  // IntegratorFilter(gain = 1): I = cumsum(g) in place   :108-109
+  tb::prefix_sum_inplace(B, ng, sc);
+  __syncthreads();
+  {  // signalstats on the integrated trace :112-115 (the init = 0 quirk: SURVEY a2)
+    const float time_min = tg, d3 = 3.f * P.dt;
+    const float stop = (minx < time_min + d3) ? time_min + d3 : minx;
+    const int from = (int)nearbyintf((time_min - tg) / P.dt), until = (int)nearbyintf((stop - tg) / P.dt);
+    float m = NAN, sg = NAN, sl = NAN, of = NAN;
+    if (0 <= from && from <= until && until <= ng - 1) tb::window_stats<false>(B, from, until, tg, P.dt, sc, &m, &sg, &sl, &of);
+    put(S_blmean, m); put(S_blsigma, sg); put(S_blslope, sl); put(S_bloffset, of);
+    tb::window_stats<false>(B, 0, ng - 1, tg, P.dt, sc, &m, &sg, &sl, &of);
+    put(S_wfmean, m); put(S_wfsigma, sg); put(S_wfslope, sl); put(S_wfoffset, of);
+  }
+  // discharge detection on the flipped integrated trace (-I): SG and trap bounds, both with
+  // the SG IntersectMaximum functor   :118-120, :137-138
+  for (int v = 0; v < 2; ++v) {
+    const float lo = v ? P.trap_min_dc : P.sg_min_dc, hi = v ? P.trap_max_dc : P.sg_max_dc;
+    const float ns = v ? P.trap_nsigma_dc : P.sg_nsigma_dc;
+    const float thr = tb::mad_threshold(B, ng, lo, hi, -1.f, sc);
+    put(v ? S_threshold_DC_trap : S_threshold_DC, thr);
+    const float th = ns * thr;
+    tb::build_mask(B, ng, -1.f, th, bm);
+    __syncthreads();
+    const ldsp_trig_out& o = out.trig[v ? 3 : 1];
+    const size_t off = b * LDSP_MAX_TRIG;
+    const int tot = intersect_maximum_block(B, ng, -1.f, th, P.sg_mintot, P.sg_maxtot, tg, P.dt, bm, sc, LDSP_MAX_TRIG,
+                                            o.x ? o.x + off : nullptr, o.x_high ? o.x_high + off : nullptr,
+                                            o.x_tot ? o.x_tot + off : nullptr, o.max ? o.max + off : nullptr, nullptr);
+    if (tid == 0 && o.count) o.count[b] = tot;
+    __syncthreads();
+  }
+  // InvCRFilter(pz_tau) on I, then TrapezoidalChargeFilter(rt, ft)   :124-129
+  for (int i = tid; i < pad4(L); i += NT) A[i] = (i < ng) ? B[i] : 0.f;
+  __syncthreads();
+  tb::prefix_sum_inplace(A, ng, sc);
+  __syncthreads();
+  for (int i = tid; i < pad4(L); i += NT) A[i] = (i < ng) ? B[i] + P.pz_c * A[i] : 0.f;  // P
+  __syncthreads();
+  const int flen = P.trap.navg + P.trap.ngap + P.trap.navg2, nt = ng - flen + 1;
+  const float tt = tg + P.dt * (float)(flen - 1);
+  {
+    const float i1 = 1.f / (float)P.trap.navg, i2 = 1.f / (float)P.trap.navg2;
+    // SiPM shaping times are a few samples: sum the windows directly (a difference of float
+    // prefix sums would carry ulp(cumsum) / navg of error into the MAD threshold)
+    const bool direct = P.trap.navg <= 16 && P.trap.navg2 <= 16;
+    if (!direct) {
+      tb::prefix_sum_inplace(A, ng, sc);  // S = cumsum(P)
+      __syncthreads();
+    }
+    for (int k = tid; k < pad4(L); k += NT) {
+      float v = 0.f;
+      if (k < nt) {
+        if (direct) {
+          float a = 0.f, bb = 0.f;
+          for (int j = 0; j < P.trap.navg2; ++j) a += A[k + P.trap.navg + P.trap.ngap + j];
+          for (int j = 0; j < P.trap.navg; ++j) bb += A[k + j];
+          v = a * i2 - bb * i1;
+        } else {
+          const float s0 = (k > 0) ? A[k - 1] : 0.f;
+          v = (A[k + flen - 1] - A[k + P.trap.navg + P.trap.ngap - 1]) * i2 - (A[k + P.trap.navg - 1] - s0) * i1;
+        }
+      }
+      B[k] = v;
+    }
+  }
+  __syncthreads();
+  // trap triggers :132-134
+  const float thr_t = tb::mad_threshold(B, nt, P.trap_min_thr, P.trap_max_thr, 1.f, sc);
+  put(S_threshold_trap, thr_t);
+  {
+    const float th = P.trap_nsigma * thr_t;
+    tb::build_mask(B, nt, 1.f, th, bm);
+    __syncthreads();
+    const ldsp_trig_out& o = out.trig[2];
+    const size_t off = b * LDSP_MAX_TRIG;
+    const int tot = intersect_maximum_block(B, nt, 1.f, th, P.trap_mintot, P.trap_maxtot, tt, P.dt, bm, sc, LDSP_MAX_TRIG,
+                                            o.x ? o.x + off : nullptr, o.x_high ? o.x_high + off : nullptr,
+                                            o.x_tot ? o.x_tot + off : nullptr, o.max ? o.max + off : nullptr, nullptr);
+    if (tid == 0 && o.count) o.count[b] = tot;
+  }
+}
+
+}  // namespace sipm
+}  // namespace ldsp
+
+using namespace ldsp;
+
+extern "C" int ldsp_sipm_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_sipm_params* p, const ldsp_sipm_out* out) {
+  if (!p || !out) return ldsp_fail(LDSP_ERR_INVALID_ARG, "ldsp_sipm_run: NULL argument");
+  int rc = ldsp_check_batch(c, wf, n, p->L, "ldsp_sipm_run");
+  if (rc || n == 0) return rc;
+  const int L = p->L;
+  if (!(p->dt > 0) || !(p->unit_per_us > 0)) return ldsp_fail(LDSP_ERR_INVALID_ARG, "dt and unit_per_us must be positive");
+  if (p->sg_npts < 1 || p->sg_npts > LDSP_MAX_SG_PTS || (p->sg_npts & 1) == 0 || p->sg_npts <= p->sg_degree || p->sg_npts > L)
+    return ldsp_fail(LDSP_ERR_UNSUPPORTED, "Savitzky-Golay window of %d points (degree %d) unsupported", p->sg_npts, p->sg_degree);
+  const int ng = L - p->sg_npts + 1;
+  const int flen = p->trap.navg + p->trap.ngap + p->trap.navg2;
+  if (p->trap.navg < 1 || p->trap.navg2 < 1 || p->trap.ngap < 0 || flen > ng) return ldsp_fail(LDSP_ERR_WINDOW, "trapezoid does not fit");
+  if (!(0 <= p->trunc_from && p->trunc_from <= p->trunc_until && p->trunc_until <= L - 1)) return ldsp_fail(LDSP_ERR_WINDOW, "t0_hpge_window outside the trace");
+  if (p->sg_mintot < 1 || p->sg_maxtot < 1 || p->trap_mintot < 1 || p->trap_maxtot < 1) return ldsp_fail(LDSP_ERR_INVALID_ARG, "tot values must be >= 1 sample");
+  sipm::SipmDev d;
+  memset(&d, 0, sizeof d);
+  d.L = L; d.np = p->sg_npts;
+  d.t_first = (float)p->t_first; d.dt = (float)p->dt; d.inv_upus = (float)(1.0 / p->unit_per_us);
+  d.trunc_from = p->trunc_from; d.trunc_until = p->trunc_until;
+  std::vector<double> cc;
+  if (!hm::sg_corr_coeffs(p->sg_npts, p->sg_degree, 1, cc)) return ldsp_fail(LDSP_ERR_INVALID_ARG, "Savitzky-Golay coefficients");
+  for (int i = 0; i < p->sg_npts; ++i) d.sg_c[i] = (float)cc[i];
+  d.sg_mintot = p->sg_mintot; d.sg_maxtot = p->sg_maxtot;
+  d.sg_min_thr = (float)p->sg_min_thr; d.sg_max_thr = (float)p->sg_max_thr; d.sg_nsigma = (float)p->sg_nsigma;
+  d.sg_min_dc = (float)p->sg_min_dc_thr; d.sg_max_dc = (float)p->sg_max_dc_thr; d.sg_nsigma_dc = (float)p->sg_nsigma_dc;
+  d.pz_c = (float)p->pz_c; d.trap = p->trap;
+  d.trap_mintot = p->trap_mintot; d.trap_maxtot = p->trap_maxtot;
+  d.trap_min_thr = (float)p->trap_min_thr; d.trap_max_thr = (float)p->trap_max_thr; d.trap_nsigma = (float)p->trap_nsigma;
+  d.trap_min_dc = (float)p->trap_min_dc_thr; d.trap_max_dc = (float)p->trap_max_dc_thr; d.trap_nsigma_dc = (float)p->trap_nsigma_dc;
+  sipm::SipmOutDev od;
+  static_assert(sizeof(ldsp_sipm_out) == sizeof(void*) * sipm::S_NCOLS + 4 * sizeof(ldsp_trig_out), "ldsp_sipm_out layout");
+  memcpy(od.col, out, sizeof(void*) * sipm::S_NCOLS);
+  od.trig[0] = out->trig; od.trig[1] = out->trig_DC; od.trig[2] = out->trig_trap; od.trig[3] = out->trig_DC_trap;
+  const size_t p4 = (size_t)(((L + 3) & ~3) + 64);
+  const size_t bytes = 2 * p4 * 4 + (size_t)(((L + 31) >> 5) + 2) * 4 + 16 + sizeof(tb::Scratch);
+  if (bytes > 160 * 1024) return ldsp_fail(LDSP_ERR_UNSUPPORTED, "dsp_sipm keeps two arrays of the trace in LDS: L <= ~19800 (got %d)", L);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sipm::k_sipm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  const int nt = L <= 4096 ? 256 : (L <= 8192 ? 512 : 1024);
+  if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  hipLaunchKernelGGL(sipm::k_sipm, dim3((unsigned)n), dim3(nt), bytes, c->stream, wf, d, od);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ldsp_fail(LDSP_ERR_HIP, "launch: %s", hipGetErrorString(e));
+  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; }
+  return LDSP_OK;
+}

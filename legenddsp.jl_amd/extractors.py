@@ -1,0 +1,226 @@
+"""Feature extractors — callable structs / functions returning per-trace columns.
+
+The reference's extractors take one waveform and return a NamedTuple; broadcast over
+an ArrayOfRDWaveforms yields a struct-of-arrays whose fields are columns
+(`inters.x`, `estats.max`, reference src/dsp_routines.jl:21, src/dsp_sipm.jl:149).  Here a
+call on a batch returns a dict of [n] device tensors directly; ragged fields come back as
+`VectorOfVectors` (offsets + values).  Times are floats in ns.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _abi, _lib
+from .config import nsamples, window_index, WindowError
+from .routines import ArrayOfRDWaveforms
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _prep(w: ArrayOfRDWaveforms):
+    x = w.signal
+    if not x.is_cuda:
+        raise _lib.LdspError(-103, "extractors need device-resident waveforms (no CPU fallback)")
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.to(torch.float32).contiguous()
+    ctx = _lib.default_context(x.device.index)
+    ctx.bind_stream()
+    return ctx, x
+
+
+def _f(n, dev):
+    return torch.empty(n, dtype=torch.float32, device=dev)
+
+
+def _i(n, dev):
+    return torch.empty(n, dtype=torch.int32, device=dev)
+
+
+def _window(w, start, stop):
+    a, b = window_index(start, w.t_first, w.dt), window_index(stop, w.t_first, w.dt)
+    if not (0 <= a <= b <= w.nsamples - 1):
+        raise WindowError(f"window [{a},{b}] outside a trace of {w.nsamples} samples")  # the reference's @assert
+    return a, b
+
+
+def _per_trace(v, n, dev):
+    if isinstance(v, torch.Tensor):
+        return v.to(device=dev, dtype=torch.float32).contiguous()
+    return torch.full((n,), float(v), dtype=torch.float32, device=dev)
+
+
+@dataclass
+class VectorOfVectors:
+    """ArraysOfArrays.VectorOfVectors: `values[offsets[i]:offsets[i+1]]` is element i."""
+    offsets: torch.Tensor
+    values: torch.Tensor
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def __getitem__(self, i):
+        return self.values[int(self.offsets[i]):int(self.offsets[i + 1])]
+
+
+def _compact(slab: torch.Tensor, count: torch.Tensor) -> VectorOfVectors:
+    cap = slab.shape[1]
+    kept = count.clamp(max=cap).to(torch.int64)
+    offsets = torch.zeros(len(count) + 1, dtype=torch.int64, device=slab.device)
+    offsets[1:] = torch.cumsum(kept, 0)
+    mask = torch.arange(cap, device=slab.device)[None, :] < kept[:, None]
+    return VectorOfVectors(offsets, slab[mask])
+
+
+def signalstats(w: ArrayOfRDWaveforms, start, stop):
+    """`signalstats(wf, start, stop)` -> mean, sigma, slope, offset."""
+    ctx, x = _prep(w)
+    a, b = _window(w, start, stop)
+    n, dev = x.shape[0], x.device
+    o = [_f(n, dev) for _ in range(4)]
+    _lib.check(_lib.lib().ldsp_signalstats(ctx.handle, _vp(x), n, x.shape[1], a, b, w.t_first, w.dt, *[_vp(t) for t in o]))
+    return dict(mean=o[0], sigma=o[1], slope=o[2], offset=o[3])
+
+
+def tailstats(w: ArrayOfRDWaveforms, start, stop):
+    """`tailstats(wf, start, stop)` -> mean, sigma, τ (reference src/tailstats.jl:13-72)."""
+    ctx, x = _prep(w)
+    a, b = _window(w, start, stop)
+    n, dev = x.shape[0], x.device
+    o = [_f(n, dev) for _ in range(3)]
+    _lib.check(_lib.lib().ldsp_tailstats(ctx.handle, _vp(x), n, x.shape[1], a, b, w.t_first, w.dt, *[_vp(t) for t in o]))
+    return {"mean": o[0], "sigma": o[1], "τ": o[2]}
+
+
+def extremestats(w: ArrayOfRDWaveforms, start=None, stop=None):
+    """`extremestats(wf[, start, stop])` -> min, max, tmin, tmax (reference src/extremestats.jl:14-40)."""
+    ctx, x = _prep(w)
+    if start is None:
+        a, b = 0, w.nsamples - 1
+    else:
+        a, b = _window(w, start, stop)
+    n, dev = x.shape[0], x.device
+    o = [_f(n, dev) for _ in range(4)]
+    _lib.check(_lib.lib().ldsp_extremestats(ctx.handle, _vp(x), n, x.shape[1], a, b, w.t_first, w.dt, *[_vp(t) for t in o]))
+    return dict(min=o[0], max=o[1], tmin=o[2], tmax=o[3])
+
+
+def thresholdstats(w: ArrayOfRDWaveforms, min=-float("inf"), max=float("inf")):
+    """reference src/thresholdstats.jl:14-41"""
+    ctx, x = _prep(w)
+    o = _f(x.shape[0], x.device)
+    _lib.check(_lib.lib().ldsp_thresholdstats(ctx.handle, _vp(x), x.shape[0], x.shape[1], float(min), float(max), _vp(o)))
+    return o
+
+
+def thresholdstats_mad(w: ArrayOfRDWaveforms, min=-float("inf"), max=float("inf")):
+    """reference src/thresholdstats.jl:56-71"""
+    ctx, x = _prep(w)
+    o = _f(x.shape[0], x.device)
+    _lib.check(_lib.lib().ldsp_thresholdstats_mad(ctx.handle, _vp(x), x.shape[0], x.shape[1], float(min), float(max), _vp(o)))
+    return o
+
+
+def saturation(w: ArrayOfRDWaveforms, low, high, start=None, stop=None):
+    """`saturation(wf, low, high)` / `saturation(wf, start, stop, low, high)` (reference src/saturation.jl:12-65)."""
+    ctx, x = _prep(w)
+    a, b = (0, w.nsamples - 1) if start is None else _window(w, start, stop)
+    n, dev = x.shape[0], x.device
+    o = [_i(n, dev) for _ in range(4)]
+    _lib.check(_lib.lib().ldsp_saturation(ctx.handle, _vp(x), n, x.shape[1], a, b, float(low), float(high), *[_vp(t) for t in o]))
+    return dict(low=o[0], high=o[1], max_cons_low=o[2], max_cons_high=o[3])
+
+
+def get_wvf_maximum(w: ArrayOfRDWaveforms, start, stop):
+    """reference src/interpolation.jl:21-46"""
+    ctx, x = _prep(w)
+    a, b = _window(w, start, stop)
+    o = _f(x.shape[0], x.device)
+    _lib.check(_lib.lib().ldsp_get_wvf_maximum(ctx.handle, _vp(x), x.shape[0], x.shape[1], a, b, _vp(o)))
+    return o
+
+
+@dataclass(frozen=True)
+class Intersect:
+    """`Intersect(mintot = ...)` -> (x, multiplicity); x = NaN where no crossing."""
+    mintot: float = 4.0
+
+    def __call__(self, w: ArrayOfRDWaveforms, threshold):
+        ctx, x = _prep(w)
+        n, dev = x.shape[0], x.device
+        thr = _per_trace(threshold, n, dev)
+        min_n = max(1, nsamples(self.mintot, w.dt))
+        xo, mult = _f(n, dev), _i(n, dev)
+        _lib.check(_lib.lib().ldsp_intersect(ctx.handle, _vp(x), n, x.shape[1], w.t_first, w.dt, _vp(thr), min_n, _vp(xo), _vp(mult)))
+        return dict(x=xo, multiplicity=mult)
+
+
+@dataclass(frozen=True)
+class IntersectMaximum:
+    """`IntersectMaximum(mintot, maxtot)` (reference src/intersect_maximum.jl:11-119)."""
+    mintot: float = 4.0
+    maxtot: float = 100.0
+
+    def __call__(self, w: ArrayOfRDWaveforms, threshold):
+        ctx, x = _prep(w)
+        n, dev = x.shape[0], x.device
+        thr = _per_trace(threshold, n, dev)
+        min_n, max_n = max(1, nsamples(self.mintot, w.dt)), max(1, nsamples(self.maxtot, w.dt))
+        cap = _abi.LDSP_MAX_TRIG
+        count = _i(n, dev)
+        slabs = {k: torch.full((n, cap), float("nan"), dtype=torch.float32, device=dev) for k in ("x", "x_high", "x_tot", "max")}
+        o = _abi.TrigOut(count.data_ptr(), *[slabs[k].data_ptr() for k in ("x", "x_high", "x_tot", "max")])
+        _lib.check(_lib.lib().ldsp_intersect_maximum(ctx.handle, _vp(x), n, x.shape[1], w.t_first, w.dt, _vp(thr), min_n, max_n, C.byref(o)))
+        res = {k: _compact(v, count) for k, v in slabs.items()}
+        res["multiplicity"] = count
+        return res
+
+
+@dataclass(frozen=True)
+class MultiIntersect:
+    """`MultiIntersect(threshold_ratios, mintot, n, d, sampling_rate)` (reference src/multi_intersect.jl:11-125)."""
+    threshold_ratios: tuple = tuple(np.arange(0.01, 0.905, 0.01))
+    mintot: float = 4.0
+    n: int = 1
+    d: int = 1
+    sampling_rate: int = 1
+
+    def __call__(self, w: ArrayOfRDWaveforms):
+        ctx, x = _prep(w)
+        nt, dev = x.shape[0], x.device
+        r = np.ascontiguousarray(self.threshold_ratios, dtype=np.float64)
+        K = len(r)
+        min_n = max(1, nsamples(self.mintot, w.dt))
+        out = torch.empty((nt, K), dtype=torch.float32, device=dev)
+        status = _i(nt, dev)
+        _lib.check(_lib.lib().ldsp_multi_intersect(ctx.handle, _vp(x), nt, x.shape[1], w.t_first, w.dt, r.ctypes.data_as(C.c_void_p),
+                                                   K, min_n, int(self.n), int(self.d), int(self.sampling_rate), _vp(out), _vp(status)))
+        if bool((status != 0).any()):
+            raise WindowError("cannot interpolate intersect on left boundary")  # reference src/multi_intersect.jl:77-78
+        return out
+
+
+@dataclass(frozen=True)
+class PolynomialDNI:
+    degree: int
+    length: float
+
+
+@dataclass(frozen=True)
+class SignalEstimator:
+    """`SignalEstimator(PolynomialDNI(degree, length))(wf, t)` (assumption A3)."""
+    method: PolynomialDNI
+
+    def __call__(self, w: ArrayOfRDWaveforms, t):
+        ctx, x = _prep(w)
+        n, dev = x.shape[0], x.device
+        tt = _per_trace(t, n, dev)
+        est = _abi.Dni(nsamples(self.method.length, w.dt), int(self.method.degree))
+        o = _f(n, dev)
+        _lib.check(_lib.lib().ldsp_signal_estimator(ctx.handle, _vp(x), n, x.shape[1], w.t_first, w.dt, _vp(tt), est, _vp(o)))
+        return o

@@ -140,3 +140,103 @@ def dsp_icpc(data: Table, config: DSPConfig, tau: float, pars_filter: dict, f_ev
     for k in ["inTrace_intersect", "inTrace_n", "n_sat_low", "n_sat_high", "n_sat_low_cons", "n_sat_high_cons"]:
         res[k] = c[k]
     return res
+
+
+# ---------------------------------------------------------------------------
+# dsp_sipm
+
+def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None):
+    """Run the fused dsp_sipm kernel (`ldsp_sipm_run`).  Returns (scalars [20, n] float32,
+    {group: {count [n] int32, x/x_high/x_tot/max [n, LDSP_MAX_TRIG] float32}})."""
+    if not wf.is_cuda:
+        raise _lib.LdspError(-103, "sipm_run needs a device-resident waveform tensor (no CPU fallback)")
+    ctx = ctx or _lib.default_context(wf.device.index)
+    n, L = wf.shape
+    if L != params.L:
+        raise ValueError(f"waveform length {L} != params.L {params.L}")
+    wf = _as_device_f32(wf, wf.device)
+    dev = wf.device
+    sc = torch.full((len(_abi.SIPM_SCALAR_COLS), n), float("nan"), dtype=torch.float32, device=dev)
+    o = _abi.SipmOut()
+    for i, c in enumerate(_abi.SIPM_SCALAR_COLS):
+        setattr(o, c, sc[i].data_ptr())
+    trig = {}
+    cap = _abi.LDSP_MAX_TRIG
+    for g in _abi.SIPM_TRIG_GROUPS:
+        cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+        slabs = {k: torch.full((n, cap), float("nan"), dtype=torch.float32, device=dev) for k in ("x", "x_high", "x_tot", "max")}
+        setattr(o, g, _abi.TrigOut(cnt.data_ptr(), slabs["x"].data_ptr(), slabs["x_high"].data_ptr(),
+                                   slabs["x_tot"].data_ptr(), slabs["max"].data_ptr()))
+        trig[g] = dict(count=cnt, **slabs)
+    ctx.bind_stream()
+    _lib.check(_lib.lib().ldsp_sipm_run(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params), C.byref(o)))
+    return sc, trig
+
+
+def dsp_sipm(data: Table, config: dict, pars_optimization: dict, ctx: _lib.Context = None) -> Table:
+    """`dsp_sipm(data::Table, config::PropDict, pars_optimization::PropDict)` — reference
+    src/dsp_sipm.jl:47-158: 24 scalar columns (4 passthrough) + 12 ragged VectorOfVectors columns,
+    names as at dsp_sipm.jl:141-157.  Trigger times are in the time-axis unit (ns)."""
+    from .extractors import _compact
+    wvfs: ArrayOfRDWaveforms = data["waveform"]
+    params = lower_sipm(config, pars_optimization, wvfs.nsamples, wvfs.t_first, wvfs.dt)
+    sc, trig = sipm_run(wvfs.signal, params, ctx)
+    s = {c: sc[i] for i, c in enumerate(_abi.SIPM_SCALAR_COLS)}
+    res = Table()
+    res["blfc"] = data["baseline"]; res["timestamp"] = data["timestamp"]
+    res["eventID_fadc"] = data["eventnumber"]; res["e_fc"] = data["daqenergy"]
+    for k in ["t_max", "t_min", "t_max_lar", "t_min_lar", "e_max", "e_min", "e_max_lar", "e_min_lar",
+              "blmean", "blsigma", "blslope", "bloffset", "wfmean", "wfsigma", "wfslope", "wfoffset"]:
+        res[k] = s[k]
+    vv = lambda g, f: _compact(trig[g][f], trig[g]["count"])
+    res["threshold"] = s["threshold"]; res["threshold_DC"] = s["threshold_DC"]
+    res["trig_pos"] = vv("trig", "x"); res["trig_max"] = vv("trig", "max")
+    res["trig_pos_DC"] = vv("trig_DC", "x"); res["trig_max_DC"] = vv("trig_DC", "max")
+    res["threshold_trap"] = s["threshold_trap"]; res["threshold_DC_trap"] = s["threshold_DC_trap"]
+    res["trig_pos_trap"] = vv("trig_trap", "x"); res["trig_pos_high_trap"] = vv("trig_trap", "x_high")
+    res["trig_pos_tot_trap"] = vv("trig_trap", "x_tot"); res["trig_max_trap"] = vv("trig_trap", "max")
+    res["trig_pos_DC_trap"] = vv("trig_DC_trap", "x"); res["trig_pos_high_DC_trap"] = vv("trig_DC_trap", "x_high")
+    res["trig_pos_tot_DC_trap"] = vv("trig_DC_trap", "x_tot"); res["trig_max_DC_trap"] = vv("trig_DC_trap", "max")
+    return res
+
+
+# ---------------------------------------------------------------------------
+# L3 helper routines composed from the functors (reference src/dsp_routines.jl).  The fused
+# kernels do not call these; they are the unfused spelling of the same steps.
+
+def get_t0(wvfs_pz: ArrayOfRDWaveforms, t0_threshold: float, flt_pars=(40.0, 100.0, 2000.0), mintot=1500.0):
+    """reference src/dsp_routines.jl:9-25 — returns t0 in us, NaN -> 0."""
+    from .filters import TrapezoidalChargeFilter
+    from .extractors import Intersect
+    flt = TrapezoidalChargeFilter(*flt_pars)(wvfs_pz)
+    t0 = Intersect(mintot=mintot)(flt, t0_threshold)["x"] / 1000.0
+    return torch.nan_to_num(t0, nan=0.0)
+
+
+def get_threshold(wvfs: ArrayOfRDWaveforms, threshold, mintot=1000.0):
+    """reference src/dsp_routines.jl:33-42 — returns us, NaN -> 0."""
+    from .extractors import Intersect
+    t = Intersect(mintot=mintot)(wvfs, threshold)["x"] / 1000.0
+    return torch.nan_to_num(t, nan=0.0)
+
+
+def get_qdrift(wvfs: ArrayOfRDWaveforms, t_start_us, dt_range, pol_power=3, sign_est_length=100.0):
+    """reference src/dsp_routines.jl:51-64; `dt_range` = (first, last) of the StepRange in ns."""
+    from .filters import IntegratorFilter
+    from .extractors import SignalEstimator, PolynomialDNI
+    integ = IntegratorFilter(1.0)(wvfs)
+    est = SignalEstimator(PolynomialDNI(pol_power, sign_est_length))
+    t = t_start_us * 1000.0
+    e0, e1, e2 = est(integ, t), est(integ, t + dt_range[0]), est(integ, t + dt_range[1])
+    return (e2 - e1) - (e1 - e0)
+
+
+def get_intracePileUp(wvfs: ArrayOfRDWaveforms, sigma_threshold: float, bl_window, mintot=100.0):
+    """reference src/dsp_routines.jl:72-82."""
+    from .filters import reverse_waveform
+    from .extractors import Intersect, signalstats
+    thres = signalstats(wvfs, bl_window[0] + wvfs.t_first, bl_window[1])["sigma"] * sigma_threshold
+    thres = torch.where(thres == 0, torch.ones_like(thres), thres)
+    r = Intersect(mintot=mintot)(reverse_waveform(wvfs), thres)
+    last = wvfs.t_first + (wvfs.nsamples - 1) * wvfs.dt
+    return dict(intersect=last - r["x"], n=r["multiplicity"])

@@ -1,0 +1,207 @@
+"""Filter functors and extractors through the C ABI: the reference's own known-answer
+values (transcribed data, files named per test) and seeded-batch parity with the oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import legenddsp_jl_amd as ldsp
+
+pytestmark = pytest.mark.gpu
+DT = 16.0
+
+
+def wv(a, t_first=0.0, dt=DT):
+    a = np.atleast_2d(np.asarray(a, dtype=np.float32))
+    return ldsp.ArrayOfRDWaveforms(torch.from_numpy(a).cuda(), t_first, dt)
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+# ---- reference known answers -------------------------------------------------------
+def test_haar_reference_values():            # test/test_haar_filter.jl:6-72
+    step = np.concatenate([np.ones(128), 2 * np.ones(128)])
+    w = wv(step, 0.0, 32000.0)
+    o = ldsp.HaarAveragingFilter(2)(w)
+    assert (o.t_first, o.dt, o.nsamples) == (0.0, 64000.0, 128)
+    np.testing.assert_allclose(host(o.signal)[0], np.r_[np.full(64, math.sqrt(2)), np.full(64, math.sqrt(8))], rtol=2e-7)
+    o2 = ldsp.HaarAveragingFilter(2)(o)
+    assert (o2.dt, o2.nsamples) == (128000.0, 64)
+    np.testing.assert_allclose(host(o2.signal)[0], np.r_[np.full(32, 2.0), np.full(32, 4.0)], rtol=3e-7)
+    o4 = ldsp.HaarAveragingFilter(4)(w)
+    assert (o4.dt, o4.nsamples) == (128000.0, 64)
+    ramp = wv(np.arange(256.0), 0.0, 32000.0)
+    np.testing.assert_allclose(host(ldsp.HaarAveragingFilter(2)(ramp).signal)[0], np.arange(0.5, 255, 2) * math.sqrt(2), rtol=3e-7)
+    np.testing.assert_allclose(host(ldsp.HaarAveragingFilter(4)(ramp).signal)[0], np.arange(0.5, 253, 4) * math.sqrt(2), rtol=3e-7)
+
+
+def test_derivative_reference_values():      # test/test_derivative.jl:6-31
+    rng = np.random.default_rng(2)
+    sig = rng.random(100).astype(np.float32)
+    expect = np.r_[sig[1] - sig[0], np.diff(sig)]
+    np.testing.assert_allclose(host(ldsp.DerivativeFilter()(wv(sig)).signal)[0], expect, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(host(ldsp.DerivativeFilter(0.37)(wv(sig)).signal)[0], np.float32(0.37) * expect, rtol=1e-6, atol=1e-7)
+
+
+def test_moving_window_reference_values():   # test/test_moving_window.jl:6-24
+    sig = np.r_[np.zeros(5), np.ones(5)]
+    w = wv(sig, 0.0, 32000.0)
+    np.testing.assert_allclose(host(ldsp.MovingWindowFilter(64000.0)(w).signal)[0], [0, 0, 0, 0, 0, .5, 1, 1, 1, 1], atol=1e-6)
+    np.testing.assert_allclose(host(ldsp.MovingWindowMultiFilter(64000.0)(w).signal)[0], [0, 0, 0, 0, .125, .5, .875, 1, 1, 1], atol=1e-6)
+
+
+def test_extremestats_reference_values():    # test/test_stats.jl:9-54
+    y = np.sin(np.deg2rad(np.arange(0, 361)))
+    y[[0, 180, 360]] = 0.0; y[90] = 1.0; y[270] = -1.0
+    w = wv(y, 0.0, 1.0)
+    e = {k: float(v[0]) for k, v in ldsp.extremestats(w).items()}
+    assert (e["min"], e["max"], e["tmin"], e["tmax"]) == (-1.0, 1.0, 270.0, 90.0)
+    e = {k: float(v[0]) for k, v in ldsp.extremestats(w, 0.0, 180.0).items()}
+    assert (e["min"], e["max"], e["tmin"], e["tmax"]) == (0.0, 1.0, 0.0, 90.0)
+    e = {k: float(v[0]) for k, v in ldsp.extremestats(w, 135.0, 225.0).items()}
+    assert e["min"] == pytest.approx(-math.sqrt(0.5), abs=1e-7) and (e["tmin"], e["tmax"]) == (225.0, 135.0)
+    with pytest.raises(ldsp.WindowError):    # the reference's @assert on windows outside the trace
+        ldsp.extremestats(w, 0.0, 400.0)
+
+
+def test_thresholdstats_mad_reference_values():   # test/test_thresholdstats.jl:7-65
+    assert float(ldsp.thresholdstats_mad(wv(np.full(100, 5.0)), -10.0, 10.0)[0]) == pytest.approx(0.0, abs=1e-7)
+    sym = np.r_[np.full(50, -1.0), np.full(50, 1.0)]
+    assert float(ldsp.thresholdstats_mad(wv(sym), -5.0, 5.0)[0]) == pytest.approx(1.4826, abs=1e-6)
+    out = np.zeros(1000); out[499:510] = 1000.0
+    assert float(ldsp.thresholdstats_mad(wv(out))[0]) < 1.0
+    assert float(ldsp.thresholdstats_mad(wv(np.full(100, 5.0)), 10.0, 20.0)[0]) == 0.0
+
+
+def test_get_wvf_maximum_reference_values():      # test/test_interpolation.jl:6-45
+    n = 100
+    s = np.zeros(n); s[:4] = [1.0, 0.8, 0.5, 0.2]
+    assert float(ldsp.get_wvf_maximum(wv(s), 0.0, 64.0)[0]) == 1.0
+    s = np.zeros(n); s[-4:] = [0.2, 0.5, 0.8, 1.0]
+    assert float(ldsp.get_wvf_maximum(wv(s), (n - 5) * DT, (n - 1) * DT)[0]) == 1.0
+    s = np.zeros(n); s[49:52] = [0.5, 1.0, 0.5]
+    assert float(ldsp.get_wvf_maximum(wv(s), 47 * DT, 53 * DT)[0]) == 1.0
+
+
+def test_intersect_maximum_reference_values():    # test/test_intersect_maximum.jl:6-107
+    n = 6200
+    tend = (n - 1) * DT
+    f = ldsp.IntersectMaximum(mintot=2 * DT, maxtot=100 * DT)
+    s = np.zeros(n); s[1:4] = [0.5, 0.6, 0.2]
+    r = f(wv(s), 0.4)
+    assert int(r["multiplicity"][0]) == 1 and len(r["x"][0]) == 1
+    assert float(r["x"][0][0]) == pytest.approx(12.8, abs=1e-4)
+    assert float(r["x_high"][0][0]) == pytest.approx(40.0, abs=1e-4)
+    assert float(r["max"][0][0]) == pytest.approx(0.6225, abs=1e-6)
+    assert float(r["x_tot"][0][0]) == pytest.approx(27.2, abs=1e-4)
+    s = np.zeros(n); s[-5:] = [0.3, 0.5, 0.6, 0.8, 1.0]
+    r = ldsp.IntersectMaximum(mintot=2 * DT, maxtot=5 * DT)(wv(s), 0.4)
+    assert int(r["multiplicity"][0]) == 1 and float(r["max"][0][0]) == 1.0
+    s = np.zeros(n); s[-3:] = [0.3, 0.5, 0.6]
+    r = f(wv(s), 0.4)
+    assert int(r["multiplicity"][0]) == 1 and float(r["x_high"][0][0]) == pytest.approx(tend, rel=1e-7)
+    s = np.zeros(n); s[99:105] = 0.8; s[199:215] = 0.9
+    r = f(wv(s), 0.4)
+    assert int(r["multiplicity"][0]) == 2 and float(r["x_tot"][0][1]) > float(r["x_tot"][0][0]) > 0
+    r = f(wv(np.zeros(n)), 0.4)                  # no crossing: empty vectors
+    assert int(r["multiplicity"][0]) == 0 and len(r["x"][0]) == 0
+
+
+def test_multi_intersect_reference_values():      # test/test_multiintersect.jl:7-27
+    y = np.arange(1.0, 101.0)
+    w = wv(y, 1.0, 1.0)
+    one = ldsp.MultiIntersect(threshold_ratios=(0.5,), mintot=1.0)(w)
+    ref = ldsp.Intersect(mintot=1.0)(w, 50.0)
+    assert float(one[0, 0]) == pytest.approx(float(ref["x"][0]), rel=1e-6) == pytest.approx(50.0, rel=1e-6)
+    res = ldsp.MultiIntersect(threshold_ratios=tuple(np.arange(0.1, 0.95, 0.1)), mintot=1.0)(w)
+    np.testing.assert_allclose(host(res)[0], np.arange(10.0, 91.0, 10.0), rtol=1e-5)
+
+
+# ---- seeded-batch parity with the oracle -----------------------------------------------
+@pytest.fixture(scope="module")
+def batch():
+    wf = ldsp.synth.hpge_batch(96, 8192, device="cuda", seed=5)
+    blm = wf[:, :2000].mean(dim=1, keepdim=True)
+    return ldsp.ArrayOfRDWaveforms((wf - blm).contiguous(), 0.0, DT)
+
+
+def _each(batch, fn):
+    x = host(batch.signal).astype(np.float64)
+    return [fn(x[i]) for i in range(x.shape[0])]
+
+
+def test_filters_match_oracle(orc, batch):
+    p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, 8192, 0.0, DT)
+    cases = [
+        (ldsp.InvCRFilter(500 * ldsp.us), lambda x: orc.invcr(x, DT / 500e3), 2e-6),
+        (ldsp.IntegratorFilter(1.0), lambda x: orc.integrator(x), 2e-6),
+        (ldsp.TrapezoidalChargeFilter(10 * ldsp.us, 4 * ldsp.us), lambda x: orc.trap(x, 625, 250), 2e-5),
+        (ldsp.TrapezoidalChargeFilter(40.0, 100.0, 2000.0), lambda x: orc.trap(x, 2, 6, 125), 5e-5),
+        (ldsp.SavitzkyGolayFilter(100.0, 3, 1), lambda x: orc.fir(x, orc.sg_coeffs(7, 3, 1)), 2e-5),
+        (ldsp.CUSPChargeFilter(5 * ldsp.us, 2.5 * ldsp.us, 1e7 * ldsp.us, 38 * ldsp.us, 2375.0), lambda x: orc.fir(x, orc.cusp_coeffs(p.cusp)), 5e-5),
+        (ldsp.ZACChargeFilter(5 * ldsp.us, 2.5 * ldsp.us, 1e7 * ldsp.us, 38 * ldsp.us, 2375.0), lambda x: orc.fir(x, orc.zac_coeffs(p.zac)), 5e-5),
+        (ldsp.DerivativeFilter(2.0), lambda x: orc.derivative(x, 2.0), 1e-6),
+        (ldsp.HaarAveragingFilter(3), lambda x: orc.haar(x, 3), 1e-6),
+        (ldsp.MovingWindowFilter(800.0), lambda x: orc.moving_window(x, 50), 2e-5),
+        (ldsp.MovingWindowMultiFilter(800.0), lambda x: orc.moving_window_multi(x, 50), 5e-5),
+    ]
+    for flt, ofn, tol in cases:
+        out = flt(batch)
+        exp = np.stack(_each(batch, ofn))
+        assert out.nsamples == exp.shape[1], type(flt).__name__
+        scale = np.abs(exp).max()
+        np.testing.assert_allclose(host(out.signal), exp, rtol=0, atol=tol * scale, err_msg=type(flt).__name__)
+    tr = ldsp.TrapezoidalChargeFilter(10 * ldsp.us, 4 * ldsp.us)(batch)
+    assert tr.t_first == (1500 - 1) * DT       # trailing time axis (A1)
+    tt = ldsp.TruncateFilter(47 * ldsp.us, 53 * ldsp.us)(batch)
+    assert (tt.nsamples, tt.t_first) == (3312 - 2938 + 1, 2938 * DT)
+    np.testing.assert_array_equal(host(tt.signal), host(batch.signal)[:, 2938:3313])
+    np.testing.assert_array_equal(host(ldsp.reverse_waveform(batch).signal), host(batch.signal)[:, ::-1])
+    np.testing.assert_allclose(host(ldsp.multiply_waveform(batch, -1.0).signal), -host(batch.signal))
+
+
+def test_extractors_match_oracle(orc, batch):
+    x = host(batch.signal).astype(np.float64)
+    n = x.shape[0]
+    ss = ldsp.signalstats(batch, 0.0, 39 * ldsp.us)
+    ts = ldsp.tailstats(batch, 70 * ldsp.us, 110 * ldsp.us)
+    es = ldsp.extremestats(batch)
+    sat = ldsp.saturation(batch, 0.0, 65520.0)
+    for i in range(0, n, 7):
+        o = orc.signalstats(x[i], 0, 2438, 0.0, DT)
+        assert float(ss["mean"][i]) == pytest.approx(o["mean"], abs=2e-4)
+        assert float(ss["sigma"][i]) == pytest.approx(o["sigma"], rel=2e-5)
+        assert float(ss["slope"][i]) == pytest.approx(o["slope"], abs=1e-8)
+        o = orc.tailstats(x[i], 4375, 6875, 0.0, DT)
+        assert float(ts["τ"][i]) == pytest.approx(o["tau"], rel=1e-4)
+        o = orc.extremestats(x[i], t_first=0.0, dt=DT)
+        assert (float(es["max"][i]), float(es["tmax"][i])) == (pytest.approx(o["max"]), o["tmax"])
+        assert float(ldsp.thresholdstats(batch, -5.0, 5.0)[i]) == pytest.approx(orc.thresholdstats(x[i], -5.0, 5.0), rel=1e-5)
+    mad = host(ldsp.thresholdstats_mad(batch, -8.0, 8.0))
+    for i in range(n):
+        assert mad[i] == pytest.approx(orc.thresholdstats_mad(x[i], -8.0, 8.0), rel=2e-6), i
+    for i in range(n):
+        o = orc.saturation(x[i], 0.0, 65520.0)
+        assert (int(sat["low"][i]), int(sat["high"][i]), int(sat["max_cons_low"][i]), int(sat["max_cons_high"][i])) == \
+               (o["low"], o["high"], o["max_cons_low"], o["max_cons_high"])
+    thr = batch.signal.amax(dim=1) * 0.5
+    r = ldsp.Intersect(mintot=32.0)(batch, thr)
+    est = ldsp.SignalEstimator(ldsp.PolynomialDNI(3, 700.0))(batch, r["x"] + 3000.0)
+    for i in range(n):
+        o = orc.intersect(x[i], float(thr[i]), 2, 0.0, DT)
+        assert float(r["x"][i]) == pytest.approx(o["x"], abs=0.01) and int(r["multiplicity"][i]) == o["multiplicity"]
+        assert float(est[i]) == pytest.approx(orc.signal_estimator(x[i], o["x"] + 3000.0, 44, 3, 0.0, DT), rel=2e-5)
+    # unfused L3 helpers agree with the fused table
+    p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, 8192, 0.0, DT)
+    raw = ldsp.synth.hpge_batch(96, 8192, device="cuda", seed=5)
+    fused = ldsp.table_columns(ldsp.icpc_run(raw, p))
+    pzd = ldsp.InvCRFilter(500 * ldsp.us)(ldsp.shift_waveform(ldsp.ArrayOfRDWaveforms(raw, 0.0, DT), -fused["blmean"]))
+    t0 = ldsp.get_t0(pzd, 4.0)
+    np.testing.assert_allclose(host(t0), host(fused["t0"]), atol=5e-4)
+    t50 = ldsp.get_threshold(pzd, fused["e_max"] * 0.5, mintot=32.0)
+    np.testing.assert_allclose(host(t50), host(fused["t50"]), atol=5e-4)
+    qd = ldsp.get_qdrift(pzd, fused["t0"], (2500.0, 5000.0))
+    np.testing.assert_allclose(host(qd), host(fused["qdrift"]), rtol=2e-4, atol=40)

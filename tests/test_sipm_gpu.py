@@ -1,0 +1,77 @@
+"""Parity of the fused HIP dsp_sipm kernel with the CPU oracle + the reference's smoke properties."""
+import numpy as np
+import pytest
+import torch
+
+import legenddsp_jl_amd as ldsp
+
+pytestmark = pytest.mark.gpu
+TRIG_FIELDS = ("x", "x_high", "x_tot", "max")
+
+
+def _compare(sc, trig, ora, n, atol_time=0.05):
+    bad = 0
+    for i, c in enumerate(ldsp._abi.SIPM_SCALAR_COLS):
+        a, b = sc[i].cpu().numpy().astype(np.float64), ora[c]
+        tol = 5e-4 + 2e-5 * np.abs(b) if c.startswith(("e_", "thr", "bl", "wf")) else 1e-3
+        if c in ("blslope", "wfslope"):
+            tol = 1e-7 + 1e-4 * np.abs(b)
+        if c in ("wfmean", "wfsigma", "wfoffset", "blmean", "bloffset", "blsigma"):
+            tol = 2e-3 + 1e-4 * np.abs(b)
+        m = ~(np.abs(a - b) <= tol) & ~(np.isnan(a) & np.isnan(b))
+        assert m.sum() <= max(1, n // 100), (c, a[m][:4], b[m][:4])
+    for g in ldsp._abi.SIPM_TRIG_GROUPS:
+        cg, co = trig[g]["count"].cpu().numpy(), ora[g]["count"]
+        same = cg == co
+        bad += int((~same).sum())
+        for f in TRIG_FIELDS:
+            a, b = trig[g][f].cpu().numpy().astype(np.float64), ora[g][f]
+            tol = atol_time if f != "max" else 1e-3 + 1e-4 * np.abs(np.nan_to_num(b))
+            ok = (np.abs(a - b) <= tol) | (np.isnan(a) & np.isnan(b))
+            bad += int((~ok[same]).any(axis=1).sum())
+    return bad
+
+
+def test_sipm_matches_oracle(orc):
+    n, L = 256, 16384
+    p = ldsp.lower_sipm(ldsp.reference_test_sipm_config(), {"sg": {"wl": 200 * ldsp.ns}}, L, 0.0, 16.0)
+    wf = ldsp.synth.sipm_batch(n, L, device="cuda")
+    sc, trig = ldsp.sipm_run(wf, p)
+    torch.cuda.synchronize()
+    ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=16)
+    assert int(trig["trig"]["count"].sum()) > n        # the synthetic batch does trigger
+    bad = _compare(sc, trig, ora, n)
+    assert bad <= n // 50, f"{bad} traces differ (threshold-decision flips are rare, not {bad})"
+
+
+def test_sipm_reference_fixture_properties():
+    """test/test_dsp_sipm.jl:70-109: 10 identical noiseless 6250-sample pulses (L % 4 != 0)."""
+    cfg = ldsp.reference_test_sipm_config()
+    w = ldsp.synth.reference_sipm_waveform().float()[None].repeat(10, 1).cuda()
+    data = ldsp.Table(waveform=ldsp.ArrayOfRDWaveforms(w, 0.0, 16.0), baseline=torch.zeros(10),
+                      timestamp=torch.zeros(10, dtype=torch.int64), eventnumber=torch.arange(1, 11), daqenergy=torch.zeros(10))
+    res = ldsp.dsp_sipm(data, cfg, {"sg": {"wl": 200 * ldsp.ns}})
+    expected = ["blfc", "timestamp", "eventID_fadc", "e_fc", "t_max", "t_min", "t_max_lar", "t_min_lar",
+                "e_max", "e_min", "e_max_lar", "e_min_lar", "blmean", "blsigma", "blslope", "bloffset",
+                "wfmean", "wfsigma", "wfslope", "wfoffset", "threshold", "threshold_DC",
+                "trig_pos", "trig_max", "trig_pos_DC", "trig_max_DC", "threshold_trap", "threshold_DC_trap",
+                "trig_pos_trap", "trig_pos_high_trap", "trig_pos_tot_trap", "trig_max_trap",
+                "trig_pos_DC_trap", "trig_pos_high_DC_trap", "trig_pos_tot_DC_trap", "trig_max_DC_trap"]
+    assert set(expected) == set(res.columnnames) and len(res.columnnames) == 36
+    assert torch.equal(res.eventID_fadc, torch.arange(1, 11)) and bool((res.timestamp == 0).all())
+    for c in ("threshold", "threshold_trap"):
+        v = res[c].cpu()
+        assert bool(torch.isfinite(v).all()) and bool((v >= 0).all())
+    for c in ("t_max", "t_min"):
+        v = res[c].cpu()
+        assert bool(((v >= 0) & (v <= 100.0)).all())
+    assert len(res.trig_pos) == 10
+
+
+def test_sipm_matches_oracle_odd_length(orc):
+    n, L = 32, 6250
+    p = ldsp.lower_sipm(ldsp.reference_test_sipm_config(), {"sg": {"wl": 200 * ldsp.ns}}, L, 0.0, 16.0)
+    wf = ldsp.synth.sipm_batch(n, L, device="cuda", seed=9)
+    sc, trig = ldsp.sipm_run(wf, p)
+    ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=8)
+    assert _compare(sc, trig, ora, n) <= 1
