@@ -37,6 +37,7 @@ struct CuspZacDev {
   // rounded power from these tables (a float q re-multiplied 1000x drifts by 3e-5):
   float qp1[5];                    // q^e,    e = 0..4  (inside a 4-sample chunk)
   float qp4[65];                   // q^(4j), j = 0..64 (across the lanes of a wave; qp4[64] = one wave-row)
+  float qpw[65];                   // q^(256j), j = 0..64 (across wave-rows)
   float eps;                       // 1 - exp(-1/tau)
   float sc_half_den;               // beta/Lf / (2 sinh(lt/sigma))
   float sc;                        // beta/Lf

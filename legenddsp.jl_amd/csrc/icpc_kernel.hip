@@ -446,7 +446,7 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
           g = fmaf(q1, g, d[r][3]); gl[r][3] = g;
           b[r] = g;
         }
-        s4_exscan_affine_fwd<NT, R>(b, s_in, Z.qp4, reinterpret_cast<float*>(part_buf()));  // barrier: A1 reads of B1 done
+        s4_exscan_affine_fwd<NT, R>(b, s_in, Z.qp4, Z.qpw, reinterpret_cast<float*>(part_buf()));  // barrier: A1 reads of B1 done
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           float4 v;
@@ -480,7 +480,7 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
           a = fmaf(q1, a, d[r][0]); al[r][0] = a;
           b[r] = a;
         }
-        s4_exscan_affine_bwd<NT, R>(b, s_in, Z.qp4, reinterpret_cast<float*>(part_buf()));  // barrier: G reads done
+        s4_exscan_affine_bwd<NT, R>(b, s_in, Z.qp4, Z.qpw, reinterpret_cast<float*>(part_buf()));  // barrier: G reads done
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           float4 v;

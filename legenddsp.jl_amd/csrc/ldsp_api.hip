@@ -202,6 +202,7 @@ static bool make_cuspzac(const ldsp_cuspzac& p, bool zac, CuspZacDev& d) {
   const double q = std::exp(-1.0 / p.sigma), sc = p.beta / (double)p.length;
   for (int e = 0; e <= 4; ++e) d.qp1[e] = (float)std::exp(-(double)e / p.sigma);
   for (int j = 0; j <= 64; ++j) d.qp4[j] = (float)std::exp(-4.0 * j / p.sigma);
+  for (int j = 0; j <= 64; ++j) d.qpw[j] = (float)std::exp(-256.0 * j / p.sigma);
   d.eps = (float)(-std::expm1(-1.0 / p.tau));
   d.sc = (float)sc;
   d.sc_half_den = (float)(sc * 0.5 / g.den);

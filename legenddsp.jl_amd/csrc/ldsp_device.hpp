@@ -27,9 +27,12 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 // Exclusive prefix (in double) of per-chunk totals, chunk order = t + NT*r.
 // tot[r]: total of this thread's 4-sample chunk in row r.  off[r]: sum of all
 // chunks before it.  part: LDS scratch [R*NW] doubles (caller alternates buffers).
+// The R*NW (<= 64) wave-row partials are combined by a second DPP scan that every
+// wave performs redundantly on lanes 0..R*NW-1 — no serial loop, no extra barrier.
 template <int NT, int R, typename T>
 __device__ __forceinline__ void s4_exscan_sum(const T (&tot)[R], double (&off)[R], double* part, double* total) {
   constexpr int NW = NT / 64;
+  static_assert(R * NW <= 64, "wave-row partials must fit one wave");
   const int w = wave_id(), l = lane_id();
   double inc[R];
 #pragma unroll
@@ -42,27 +45,25 @@ __device__ __forceinline__ void s4_exscan_sum(const T (&tot)[R], double (&off)[R
     for (int r = 0; r < R; ++r) part[r * NW + w] = inc[r];
   }
   __syncthreads();
-  double acc = 0;
+  const double pv = (l < R * NW) ? part[l] : 0.0;
+  const double pinc = wave_incl_scan_sum_f64(pv);
+  const double pexc = pinc - pv;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    for (int ww = 0; ww < NW; ++ww) {
-      if (ww == w) off[r] = acc + (inc[r] - (double)tot[r]);
-      acc += part[r * NW + ww];
-    }
-  }
-  if (total) *total = acc;
+  for (int r = 0; r < R; ++r) off[r] = readlane_d(pexc, r * NW + w) + (inc[r] - (double)tot[r]);
+  if (total) *total = readlane_d(pinc, R * NW - 1);
 }
 
 // One-pole recursion s <- a*s + b over chunks (a = q^4 constant): state ENTERING
 // each of the thread's chunks, forward direction (state 0 before chunk 0).
 // b[r]: the chunk's own end state from zero input state.
-// qp4[j] = q^(4j), j = 0..64 (LDS or global table).
+// qp4[j] = q^(4j), j = 0..64;  qpw[j] = q^(256j), j = 0..64 (one wave-row = 256 samples).
 template <int NT, int R>
-__device__ __forceinline__ void s4_exscan_affine_fwd(const float (&b)[R], float (&s_in)[R], const float* qp4, float* part) {
+__device__ __forceinline__ void s4_exscan_affine_fwd(const float (&b)[R], float (&s_in)[R], const float* qp4, const float* qpw,
+                                                     float* part) {
   constexpr int NW = NT / 64;
   const int w = wave_id(), l = lane_id();
   const AffinePow P = {qp4[1], qp4[2], qp4[4], qp4[8]};
-  const float f15 = qp4[(l & 15) + 1], f31 = qp4[(l & 31) + 1], fl = qp4[l], aw = qp4[64];
+  const float f15 = qp4[(l & 15) + 1], f31 = qp4[(l & 31) + 1], fl = qp4[l];
   float inc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) inc[r] = wave_incl_scan_affine(b[r], P, f15, f31);
@@ -71,25 +72,26 @@ __device__ __forceinline__ void s4_exscan_affine_fwd(const float (&b)[R], float 
     for (int r = 0; r < R; ++r) part[r * NW + w] = inc[r];
   }
   __syncthreads();
-  float s = 0.f;  // state entering wave-row (r, w)
+  // scan of the wave-row end states with decay q^256 per step
+  const AffinePow PW = {qpw[1], qpw[2], qpw[4], qpw[8]};
+  const float pv = (l < R * NW) ? part[l] : 0.f;
+  const float pinc = wave_incl_scan_affine(pv, PW, qpw[(l & 15) + 1], qpw[(l & 31) + 1]);
+  const float pexc = dpp_f<0x138>(0.f, pinc);  // state at the END of the previous wave-row = state entering this one
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    float sw_in = 0.f;
-    for (int ww = 0; ww < NW; ++ww) {
-      if (ww == w) sw_in = s;
-      s = fmaf(aw, s, part[r * NW + ww]);
-    }
-    float ex = dpp_f<0x138>(0.f, inc[r]);  // wave_shr:1 — inclusive value of lane l-1 (0 for lane 0)
+    const float sw_in = readlane_f(pexc, r * NW + w);
+    const float ex = dpp_f<0x138>(0.f, inc[r]);  // wave_shr:1 — inclusive value of lane l-1 (0 for lane 0)
     s_in[r] = fmaf(fl, sw_in, ex);
   }
 }
 // Anti-causal mirror: state entering each chunk from the RIGHT (state 0 after the last chunk).
 template <int NT, int R>
-__device__ __forceinline__ void s4_exscan_affine_bwd(const float (&b)[R], float (&s_in)[R], const float* qp4, float* part) {
+__device__ __forceinline__ void s4_exscan_affine_bwd(const float (&b)[R], float (&s_in)[R], const float* qp4, const float* qpw,
+                                                     float* part) {
   constexpr int NW = NT / 64;
   const int w = wave_id(), l = lane_id();
   const float pw[6] = {qp4[1], qp4[2], qp4[4], qp4[8], qp4[16], qp4[32]};
-  const float fl = qp4[63 - l], aw = qp4[64];
+  const float fl = qp4[63 - l];
   float inc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) inc[r] = wave_incl_scan_affine_rev(b[r], pw);
@@ -98,14 +100,15 @@ __device__ __forceinline__ void s4_exscan_affine_bwd(const float (&b)[R], float 
     for (int r = 0; r < R; ++r) part[r * NW + w] = inc[r];
   }
   __syncthreads();
-  float s = 0.f;
+  // mirrored order: lane j holds the wave-row (R*NW-1-j), scanned forward with decay q^256
+  constexpr int NP = R * NW;
+  const AffinePow PW = {qpw[1], qpw[2], qpw[4], qpw[8]};
+  const float pv = (l < NP) ? part[NP - 1 - l] : 0.f;
+  const float pinc = wave_incl_scan_affine(pv, PW, qpw[(l & 15) + 1], qpw[(l & 31) + 1]);
+  const float pexc = dpp_f<0x138>(0.f, pinc);
 #pragma unroll
-  for (int r = R - 1; r >= 0; --r) {
-    float sw_in = 0.f;
-    for (int ww = NW - 1; ww >= 0; --ww) {
-      if (ww == w) sw_in = s;
-      s = fmaf(aw, s, part[r * NW + ww]);
-    }
+  for (int r = 0; r < R; ++r) {
+    const float sw_in = readlane_f(pexc, NP - 1 - (r * NW + w));
     float ex = __shfl_down(inc[r], 1, 64);
     if (l == 63) ex = 0.f;
     s_in[r] = fmaf(fl, sw_in, ex);
