@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stddef.h>
+#include <type_traits>
 #include "icpc_dev.hpp"
 #include "ldsp_device.hpp"
 
@@ -63,7 +64,7 @@ enum { FN_RAW };
 enum { IS_LOW, IS_HIGH, IS_TAILBAD, IS_CNT0 };
 constexpr int NSUM = 16;  // deterministic f64 sum sites x NW wave partials
 
-template <int NT, int R>
+template <int NT, int R, bool MASKS = true>
 struct Smem {
   static constexpr int NW = NT / 64, SP = 4 * R, Lp = NT * SP, NWORDS = Lp / 32;
   float* B0;      // [Lp]      y, later scratch
@@ -76,14 +77,15 @@ struct Smem {
   float* outv;    // [C_NCOLS]  output row, filled as results become available
   float* misc;    // [16]       small broadcasts
   static constexpr size_t bytes() {
-    return (size_t)(Lp + Lp + 64) * 4 + (size_t)NMASK * NWORDS * 4 + 2 * R * NW * 8 + NSUM * NW * 8 + sizeof(Slots) +
+    return (size_t)(Lp + Lp + 64) * 4 + (MASKS ? (size_t)NMASK * NWORDS * 4 : 0) + 2 * R * NW * 8 + NSUM * NW * 8 + sizeof(Slots) +
            R * NW * 4 + C_NCOLS * 4 + 16 * 4 + 64;
   }
-  __device__ explicit Smem(unsigned char* raw) {
+  // pad: floats of zero-filled space in front of B1 (reads at small negative indices)
+  __device__ explicit Smem(unsigned char* raw, int pad = 0) {
     B0 = reinterpret_cast<float*>(raw);
-    B1 = B0 + Lp;
+    B1 = B0 + Lp + pad;
     bm = reinterpret_cast<uint32_t*>(B1 + Lp + 64);
-    part = reinterpret_cast<double*>(bm + NMASK * NWORDS);
+    part = reinterpret_cast<double*>(bm + (MASKS ? NMASK * NWORDS : 0));
     wsum = part + 2 * R * NW;
     sl = reinterpret_cast<Slots*>(wsum + NSUM * NW);
     ylast = reinterpret_cast<float*>(sl + 1);
@@ -209,18 +211,23 @@ __device__ __forceinline__ float flt_eval_rare(const float* y, const float* c, i
 // independent of kernel 1.  It re-reads the trace (served by the Infinity Cache when
 // the host chunks the batch), takes blmean and the t50 position from kernel 1's
 // side buffer, rebuilds y = x - blmean + c*cumsum and evaluates both filters.
+// zero-filled space in front of the Dp array: the ZAC parabola taps reach back Lf+2 samples
+__host__ __device__ inline int cz_pad(const IcpcDev& P) { return ((P.cusp.Lf > P.zac.Lf ? P.cusp.Lf : P.zac.Lf) + 2 + 7) & ~3; }
+
 // WANT_C / WANT_Z: which filters this launch evaluates.  Both = they share sigma / flat /
 // length / tau (one set of recursions); otherwise the host launches the kernel once per filter.
 template <int NT, int R, bool DIRECT, bool WANT_C, bool WANT_Z>
 __global__ void __launch_bounds__(NT, 4)
 icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, const float* __restrict__ aux, IcpcOutDev out) {
-  using SM = Smem<NT, R>;
+  using SM = Smem<NT, R, false>;
   constexpr int NW = SM::NW, SP = SM::SP, Lp = SM::Lp;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const IcpcDev& P = *Pp;
   const int L = P.L, tid = threadIdx.x;
   const int lane = lane_id(), wave = wave_id();
-  SM S(smem_raw);
+  const int pad = cz_pad(P);
+  SM S(smem_raw, pad);
+  for (int i = tid; i < pad; i += NT) S.B1[i - pad] = 0.f;  // Dp[i < 0] = 0
   const float* w = wf + (size_t)blockIdx.x * (size_t)L;
   int scan_buf = 0;
   auto part_buf = [&]() { double* p = S.part + (scan_buf & 1) * R * NW; ++scan_buf; return p; };
@@ -405,21 +412,21 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
           if ((m & 1) == 1) asm volatile("" ::: "memory");  // keep at most two iterations of loads in flight
         }
         if (want_z) {
-          // u[n] = sum_e coef_e * Dp[n - shift_e]; overwrites y[k] in B0 — only this thread
-          // ever read that element (above), so in place is race-free
+          // u[n] = sum_e coef_e * Dp[n - shift_e] (Dp = 0 at negative indices: the pad), for every n.
+          // Tap-outer / row-inner: one address per tap, immediate row offsets.  Overwrites y[k] in
+          // B0 — only this thread ever read that element (above), so in place is race-free.
+          float u[SP];
+#pragma unroll
+          for (int m = 0; m < SP; ++m) u[m] = 0.f;
           const int nz = ZZ.zu_n;
-#pragma unroll 1
-          for (int m = 0; m < SP; ++m) {
-            const int k = tid + NT * m;
-            float u = 0.f;
-            if (k < L) {
-              for (int e = 0; e < nz; ++e) {
-                const int i = k - ZZ.zu_shift[e];
-                if (i > 0) u = fmaf(ZZ.zu_coef[e], S.B1[i], u);
-              }
-            }
-            S.B0[k] = u;
+          for (int e = 0; e < nz; ++e) {
+            const float ce = ZZ.zu_coef[e];
+            const float* dp = &S.B1[tid - ZZ.zu_shift[e]];
+#pragma unroll
+            for (int m = 0; m < SP; ++m) u[m] = fmaf(ce, dp[NT * m], u[m]);
           }
+#pragma unroll
+          for (int m = 0; m < SP; ++m) S.B0[tid + NT * m] = (tid + NT * m < L) ? u[m] : 0.f;
         }
       }
       // ---- d[i] = (y[i]-y[i-1]) + eps*y[i-1] for 1 <= i < L, else 0   (S4)
@@ -832,13 +839,12 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   __syncthreads();
   if (P.dbg_stop == 3) return;
   // Intersect scans on the bit-masks (thread w <-> word w)
-  if (tid < NWORDS) {
-    for (int q = 0; q < 7; ++q) {
-      const int min_n = (q < 5) ? P.tx_mintot : P.t0_mintot;
-      int c, f;
-      intersect_word(S.bm + q * NWORDS, tid, NWORDS, min_n, &c, &f);
-      if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + q], c); atomicMin(&S.sl->imin[q], f); }
-    }
+  for (int j = tid; j < 7 * NWORDS; j += NT) {
+    const int q = j / NWORDS, wd = j - q * NWORDS;
+    const int min_n = (q < 5) ? P.tx_mintot : P.t0_mintot;
+    int c, f;
+    intersect_word(S.bm + q * NWORDS, wd, NWORDS, min_n, &c, &f);
+    if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + q], c); atomicMin(&S.sl->imin[q], f); }
   }
   __syncthreads();
   {
@@ -898,23 +904,32 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
 
   // ------------------------------------------------ phase 3c: signal estimators
   // e_trap = SignalEstimator(trap_opt output, t50 + rt + ft/2)     dsp_icpc.jl:163
-  float e_trap, qdrift, lq;
+  // the seven estimates are spread over the waves (each needs a full wave: lane l = window point l)
   {
-    Pos p = pos_add(ptx[1], P.trap_pickoff);
-    p.ip -= (P.opt.flen - 1);
-    e_trap = estimate(P.sig_est, p, L - P.opt.flen + 1, [&](int i) { return trap_at(S.B1, i, P.opt); });
-    // get_qdrift (dsp_routines.jl:51-64): integrator output I[i] = T[i+1]
-    auto I = [&](int i) { return S.B1[i + 1]; };
-    const float a0 = estimate(P.int_est, pt0, L, I);
-    const float a1 = estimate(P.int_est, pos_add(pt0, P.qdrift_d1), L, I);
-    const float a2 = estimate(P.int_est, pos_add(pt0, P.qdrift_d2), L, I);
-    qdrift = (a2 - a1) - (a1 - a0);
-    const float b0 = estimate(P.int_est, ptx[2], L, I);
-    const float b1 = estimate(P.int_est, pos_add(ptx[2], P.lq_d1), L, I);
-    const float b2 = estimate(P.int_est, pos_add(ptx[2], P.lq_d2), L, I);
-    lq = (b2 - b1) - (b1 - b0);
+    float* eslot = S.misc + 4;
+    auto I = [&](int i) { return S.B1[i + 1]; };  // integrator output I[i] = T[i+1]  (dsp_routines.jl:53)
+    for (int e = wave; e < 7; e += NW) {
+      float v;
+      if (e == 0) {
+        Pos p = pos_add(ptx[1], P.trap_pickoff);
+        p.ip -= (P.opt.flen - 1);
+        v = estimate(P.sig_est, p, L - P.opt.flen + 1, [&](int i) { return trap_at(S.B1, i, P.opt); });
+      } else if (e <= 3) {  // get_qdrift(wvfs, t0, qdrift_int_length)   dsp_routines.jl:51-64
+        const float d = (e == 1) ? 0.f : (e == 2 ? P.qdrift_d1 : P.qdrift_d2);
+        v = estimate(P.int_est, pos_add(pt0, d), L, I);
+      } else {              // lq: the same from t80 with lq_int_length      dsp_icpc.jl:144
+        const float d = (e == 4) ? 0.f : (e == 5 ? P.lq_d1 : P.lq_d2);
+        v = estimate(P.int_est, pos_add(ptx[2], d), L, I);
+      }
+      if (lane == 0) eslot[e] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      S.outv[C_e_trap] = eslot[0];
+      S.outv[C_qdrift] = (eslot[3] - eslot[2]) - (eslot[2] - eslot[1]);
+      S.outv[C_lq] = (eslot[6] - eslot[5]) - (eslot[5] - eslot[4]);
+    }
   }
-  put(C_e_trap, e_trap); put(C_qdrift, qdrift); put(C_lq, lq);
   if (P.dbg_stop == 5) return;
 
   // ----------------------------------- phase 4: SG derivatives, current maxima
@@ -933,22 +948,88 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     float bv[4]; int bi[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) { bv[f] = -INFINITY; bi[f] = 0x7fffffff; }
-    for (int m = 0; m < SP; ++m) {
-      const int k = tid + NT * m;
-      float g0 = -INFINITY;
-      if (k < ng) {
-        g0 = flt_at(0, k);
-        gmax = fmaxf(gmax, g0);
-        winf_accum(sgb, P.sgbl, k, (float)k - ficg, g0);
-        if (k >= P.cur_from[0] && k <= P.cur_until[0] && g0 > bv[0]) { bv[0] = g0; bi[0] = k; }
-      }
-      S.B1[k] = g0;
+    // S4 evaluation from the register-resident y plus a halo of the next samples (ds_read_b128):
+    // all four filters share one window; taps in SGPRs, zero-padded to M.
+    auto sg_pass_s4 = [&](auto mtag) {
+      constexpr int M = decltype(mtag)::value;
+      constexpr int NH = (M - 1 + 3) / 4;
+      float c0[M], c1[M], c2[M];
 #pragma unroll
-      for (int f = 1; f < 4; ++f) {
-        if (f == 2 && P.sg_same_02) continue;
-        if (k >= P.cur_from[f] && k <= P.cur_until[f]) {
-          const float g = flt_at(f, k);
-          if (g > bv[f]) { bv[f] = g; bi[f] = k; }
+      for (int i = 0; i < M; ++i) {
+        c0[i] = (i < P.sg_npts[0]) ? P.sg_c[0][i] : 0.f;
+        c1[i] = (i < P.sg_npts[1]) ? P.sg_c[1][i] : 0.f;
+        c2[i] = (i < P.sg_npts[2]) ? P.sg_c[2][i] : 0.f;
+      }
+      const int wlo = min(min(P.cur_from[1], P.cur_from[2]), P.cur_from[3]);
+      const int whi = max(max(P.cur_until[1], P.cur_until[2]), P.cur_until[3]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int i0 = 4 * (tid + NT * r);
+        float win[4 + 4 * NH];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) win[e] = y[r][e];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          const float4 v = *reinterpret_cast<const float4*>(&S.B0[i0 + 4 + 4 * h]);  // past Lp this runs into B1: masked below
+          win[4 + 4 * h] = v.x; win[5 + 4 * h] = v.y; win[6 + 4 * h] = v.z; win[7 + 4 * h] = v.w;
+        }
+        float go[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = i0 + e;
+          float g = 0.f;
+#pragma unroll
+          for (int i = 0; i < M; ++i) g = fmaf(c0[i], win[e + i], g);
+          const bool valid = k < ng;
+          go[e] = valid ? g : -INFINITY;
+          gmax = fmaxf(gmax, go[e]);
+          winf_accum(sgb, P.sgbl, valid ? k : -1, (float)k - ficg, g);
+          if (valid && k >= P.cur_from[0] && k <= P.cur_until[0] && g > bv[0]) { bv[0] = g; bi[0] = k; }
+        }
+        *reinterpret_cast<float4*>(&S.B1[i0]) = make_float4(go[0], go[1], go[2], go[3]);
+        // SG(60 ns), SG(100 ns), plain derivative: only wave-rows that touch the current window
+        const int wfirst = 4 * ((tid & ~63) + NT * r), wlast = wfirst + 255;
+        if (wfirst <= whi && wlast >= wlo) {
+          const float ypv = (i0 > 0) ? S.B0[i0 - 1] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k = i0 + e;
+            float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < M; ++i) { g1 = fmaf(c1[i], win[e + i], g1); g2 = fmaf(c2[i], win[e + i], g2); }
+            float g3 = win[e] - (e > 0 ? win[(e + 3) & 3] : ypv);  // y[k] - y[k-1]
+            if (k == 0) g3 = win[1] - win[0];                        // y[max(i,1)] - y[max(i-1,0)] at i = 0
+            if (k >= P.cur_from[1] && k <= P.cur_until[1] && g1 > bv[1]) { bv[1] = g1; bi[1] = k; }
+            if (!P.sg_same_02 && k >= P.cur_from[2] && k <= P.cur_until[2] && g2 > bv[2]) { bv[2] = g2; bi[2] = k; }
+            if (k >= P.cur_from[3] && k <= P.cur_until[3] && g3 > bv[3]) { bv[3] = g3; bi[3] = k; }
+          }
+        }
+      }
+    };
+    const int npmax = max(P.sg_npts[0], max(P.sg_npts[1], P.sg_npts[2]));
+    if (npmax <= 7) {
+      sg_pass_s4(std::integral_constant<int, 7>{});
+    } else if (npmax <= 13) {
+      sg_pass_s4(std::integral_constant<int, 13>{});
+    } else {
+      // generic LS evaluation for long windows
+      for (int m = 0; m < SP; ++m) {
+        const int k = tid + NT * m;
+        float g0 = -INFINITY;
+        if (k < ng) {
+          g0 = flt_at(0, k);
+          gmax = fmaxf(gmax, g0);
+          winf_accum(sgb, P.sgbl, k, (float)k - ficg, g0);
+          if (k >= P.cur_from[0] && k <= P.cur_until[0] && g0 > bv[0]) { bv[0] = g0; bi[0] = k; }
+        }
+        S.B1[k] = g0;
+  #pragma unroll
+        for (int f = 1; f < 4; ++f) {
+          if (f == 2 && P.sg_same_02) continue;
+          if (k >= P.cur_from[f] && k <= P.cur_until[f]) {
+            const float g = flt_at(f, k);
+            if (g > bv[f]) { bv[f] = g; bi[f] = k; }
+          }
         }
       }
     }
@@ -1141,7 +1222,7 @@ pz_trap_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, flo
 
 template <int NT, int R>
 static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
-                                bool direct, bool cz_shared, int stop_after_main, hipStream_t st) {
+                                bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st) {
   const size_t smem = Smem<NT, R>::bytes();
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_kernel<NT, R>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1149,10 +1230,11 @@ static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, f
   hipLaunchKernelGGL((icpc_kernel<NT, R>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, aux, out);
   e = hipGetLastError();
   if (e != hipSuccess || stop_after_main) return e;
+  const size_t smem_cz = Smem<NT, R, false>::bytes() + (size_t)cz_pad_floats * 4;
   auto launch_cz = [&](auto kern) -> hipError_t {
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_cz);
     if (e2 != hipSuccess) return e2;
-    hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(NT), smem, st, wf, dP, (const float*)aux, out);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(NT), smem_cz, st, wf, dP, (const float*)aux, out);
     return hipGetLastError();
   };
   if (direct) return launch_cz(&icpc_cz_kernel<NT, R, true, true, true>);
@@ -1162,13 +1244,13 @@ static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, f
   return launch_cz(&icpc_cz_kernel<NT, R, false, false, true>);
 }
 hipError_t launch_icpc(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
-                       bool direct, bool cz_shared, int stop_after_main, hipStream_t st) {
+                       bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st) {
   switch (NT) {
-    case 64: return launch_icpc_t<64, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, st);
-    case 128: return launch_icpc_t<128, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, st);
-    case 256: return launch_icpc_t<256, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, st);
-    case 512: return launch_icpc_t<512, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, st);
-    case 1024: return launch_icpc_t<1024, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, st);
+    case 64: return launch_icpc_t<64, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st);
+    case 128: return launch_icpc_t<128, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st);
+    case 256: return launch_icpc_t<256, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st);
+    case 512: return launch_icpc_t<512, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st);
+    case 1024: return launch_icpc_t<1024, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st);
     default: return hipErrorInvalidValue;
   }
 }

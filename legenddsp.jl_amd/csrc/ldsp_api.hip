@@ -2,6 +2,7 @@
 // parameter blocks to device constants, launches.  No torch types, no CPU
 // compute fallback: every entry point either launches HIP kernels or fails.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -16,7 +17,7 @@
 
 namespace ldsp {
 hipError_t launch_icpc(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
-                       bool direct, bool cz_shared, int stop_after_main, hipStream_t st);
+                       bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st);
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 size_t icpc_smem_bytes(int NT);
 }  // namespace ldsp
@@ -355,7 +356,8 @@ int ldsp_icpc_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_param
   }
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->d_icpc, c->d_aux, od, c->icpc_host.cusp_mode == 0,
-                      c->icpc_host.cz_shared != 0, c->dbg_stop != 0, c->stream));
+                      c->icpc_host.cz_shared != 0, c->dbg_stop != 0,
+                      ((std::max(c->icpc_host.cusp.Lf, c->icpc_host.zac.Lf) + 2 + 7) & ~3), c->stream));
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; }
   return LDSP_OK;
 }

@@ -142,12 +142,16 @@ __device__ __forceinline__ void intersect_word(const uint32_t* bm, int w, int nw
   uint32_t h = bm[w];
   uint32_t prev = (w == 0) ? 1u : (bm[w - 1] >> 31);  // sample -1 counts as "high": initial run excluded
   uint32_t starts = h & ~((h << 1) | prev);
+  if (min_n >= 2) {  // cheap prune: the sample after a run start must be high too
+    const uint32_t next = (w + 1 < nwords) ? (bm[w + 1] & 1u) : 0u;
+    starts &= (h >> 1) | (next << 31);
+  }
   int c = 0, f = 0x7fffffff;
   while (starts) {
     int b = __ffs(starts) - 1;
     starts &= starts - 1;
     int s = 32 * w + b;
-    if (min_n <= 1 || bits_all_set(bm, s + 1, min_n - 1, nwords)) { ++c; f = min(f, s); }
+    if (min_n <= 2 || bits_all_set(bm, s + 2, min_n - 2, nwords)) { ++c; f = min(f, s); }
   }
   *cnt = c; *first = f;
 }
@@ -197,13 +201,24 @@ __device__ __forceinline__ void unpack_vi(unsigned long long k, float* v, int* i
   *v = ford_inv((uint32_t)(k >> 32));
   *i = 0x7fffffff - (int)(uint32_t)(k & 0xffffffffu);
 }
+// 64-bit unsigned max over the wave (DPP scan, result in every lane)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long t = __shfl_xor(k, o, 64);
-    k = t > k ? t : k;
-  }
-  return k;
+  unsigned long long t;
+  t = dpp_u64<0x111>(k); k = t > k ? t : k;
+  t = dpp_u64<0x112>(k); k = t > k ? t : k;
+  t = dpp_u64<0x114>(k); k = t > k ? t : k;
+  t = dpp_u64<0x118>(k); k = t > k ? t : k;
+  t = dpp_u64<0x142, 0xa>(k); k = t > k ? t : k;
+  t = dpp_u64<0x143, 0xc>(k); k = t > k ? t : k;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 }  // namespace ldsp
