@@ -29,6 +29,25 @@ from legenddsp_jl_amd import dist as ldist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md chip table)
 
 
+def measured_traffic(kernel, n, L):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command
+    (profiles/rNN_hbm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
+    --pmc runs, tools/profile_round.sh).  None when no pass at this batch shape is on file."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get("n_traces") != n or rec.get("L") != L:
+            continue
+        for name, v in rec.get("kernels", {}).items():
+            if name.startswith("ldsp::" + kernel + "<"):
+                return {"bytes": v["hbm_bytes_per_launch_corrected"], "source": os.path.relpath(path, ROOT)}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -37,7 +56,7 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000, help="traces per GPU")
     ap.add_argument("--L", type=int, default=8192)
     ap.add_argument("--workload", choices=["icpc", "pz_trap"], default="icpc")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="traces timed on the host cores (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=65536, help="traces timed on the host cores (0 = skip); ~10 s on 16 cores")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,7 +102,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    kernel_ms = []
+    kernel_ms, stage_ms = [], [[], []]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -98,6 +117,9 @@ def main():
         else:
             ldsp.icpc_pz_trap_run(wf, params, ctx, out=out)
         kernel_ms.append(ctx.last_kernel_ms())
+        if args.workload == "icpc":
+            stage_ms[0].append(ctx.last_stage_ms(0))
+            stage_ms[1].append(ctx.last_stage_ms(1))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -107,8 +129,21 @@ def main():
         total = n * world * args.steps
         wps = total / elapsed
         kms = sum(kernel_ms) / len(kernel_ms)
-        bytes_per_trace = 4 * L + (4 * ncol if args.workload == "icpc" else 8)
-        achieved = n * bytes_per_trace / (kms * 1e-3) / 1e9
+        # one trace read + one output row written.  dsp_icpc runs as two kernels
+        # (DESIGN.md §kernels); the roofline entry is for the dominant one, icpc_kernel, which
+        # reads the trace (4L), writes 42 columns and a 16-byte hand-over record; icpc_cz_kernel
+        # reads the trace again plus that record and writes the 6 CUSP/ZAC columns.
+        chain_bytes = 4 * L + (4 * ncol if args.workload == "icpc" else 8)
+        if args.workload == "icpc":
+            k1 = sum(stage_ms[0]) / len(stage_ms[0])
+            k2 = sum(stage_ms[1]) / len(stage_ms[1])
+            bytes_per_trace = 4 * L + 4 * 42 + 16
+            dom_ms = k1
+        else:
+            bytes_per_trace, dom_ms = chain_bytes, kms
+        achieved = n * bytes_per_trace / (dom_ms * 1e-3) / 1e9
+        dom_kernel = "icpc_kernel" if args.workload == "icpc" else "pz_trap_kernel"
+        traffic = measured_traffic(dom_kernel, n, L)
         res = {
             "metric": "waveforms/s, full dsp_icpc chain, 8192-sample f32" if args.workload == "icpc"
             else "waveforms/s, pole-zero + trapezoid sub-chain, 8192-sample f32",
@@ -125,9 +160,16 @@ def main():
                        "gather": "rccl gather of [n,48] f32 to rank 0" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "icpc_kernel" if args.workload == "icpc" else "pz_trap_kernel",
-                         "kernel_ms": kms, "algorithmic_bytes_per_trace": bytes_per_trace},
+                         "kernel": dom_kernel,
+                         "kernel_ms": dom_ms, "algorithmic_bytes_per_trace": bytes_per_trace},
         }
+        if traffic:
+            res["roofline"]["traffic"] = traffic["bytes"]
+            res["roofline"]["traffic_source"] = traffic["source"]
+        if args.workload == "icpc":
+            res["roofline"]["chain"] = {  # both kernels together against the path's algorithmic bytes
+                "kernels_ms": {"icpc_kernel": k1, "icpc_cz_kernel": k2}, "algorithmic_bytes_per_trace": chain_bytes,
+                "achieved": n * chain_bytes / (kms * 1e-3) / 1e9, "frac": n * chain_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and args.cpu_sample > 0 and args.workload == "icpc":
             from oracle import oracle as orc  # checker / CPU baseline only
             orc.build()

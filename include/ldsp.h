@@ -71,6 +71,9 @@ int64_t ldsp_abi_sizeof(int which);
  * been enabled; synchronises on the closing event). */
 int ldsp_ctx_enable_timing(ldsp_ctx* ctx, int on);
 int ldsp_ctx_last_kernel_ms(ldsp_ctx* ctx, float* ms);
+/* Per-kernel split of the last ldsp_icpc_run: stage 0 = icpc_kernel (phases up to the
+ * Intersect family), stage 1 = icpc_cz_kernel (CUSP/ZAC).  Other calls have one stage. */
+int ldsp_ctx_last_stage_ms(ldsp_ctx* ctx, int stage, float* ms);
 
 /* ---- limits of the built kernels --------------------------------------- */
 #define LDSP_MAX_L 32768        /* samples per trace                          */

@@ -143,6 +143,24 @@ __device__ __forceinline__ void winf_accum(WinAccF& a, const WinDev& w, int i, f
   a.sx = fmaf(xm, vm, a.sx);
   a.sxi += xm;
 }
+// four consecutive samples i0..i0+3 at once; rows outside the window cost one test
+__device__ __forceinline__ void winf_accum4(WinAccF& a, const WinDev& w, int i0, float xi0, float v0, float v1, float v2, float v3) {
+  const int lo = max(w.from - i0, 0), hi = min(w.until - i0, 3);  // in-window e in [lo, hi]
+  if (lo > hi) return;
+  if (a.n == 0.f) a.p = (lo == 0) ? v0 : (lo == 1) ? v1 : (lo == 2) ? v2 : v3;
+  const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float m = (e >= lo && e <= hi) ? 1.f : 0.f;
+    const float d = (v[e] - a.p) * m;
+    const float xm = (xi0 + (float)e) * m;
+    a.n += m;
+    a.s1 += d;
+    a.s2 = fmaf(d, d, a.s2);
+    a.sx = fmaf(xm, d, a.sx);
+    a.sxi += xm;
+  }
+}
 __device__ __forceinline__ WinAcc winf_rebase(const WinAccF& a) {
   const double p = (double)a.p, n = (double)a.n, s1 = (double)a.s1;
   WinAcc r;
@@ -630,8 +648,8 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
         n_high += (ok && v == P.sat_high);
         rmax = fmaxf(rmax, ok ? v : -INFINITY);
         rmin = fminf(rmin, ok ? v : INFINITY);
-        winf_accum(bl, P.bl, i, xi0 + (float)e, v);
       }
+      winf_accum4(bl, P.bl, i0, xi0, x[r][0], x[r][1], x[r][2], x[r][3]);
     }
     win_publish<NW>(winf_rebase(bl), S.wsum, 0);
     n_low = wave_sum_all_i(n_low); n_high = wave_sum_all_i(n_high);
@@ -709,16 +727,16 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       const bool wave_in = (wfirst <= P.tail.until) && (wlast >= P.tail.from);
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[r][e] = (i0 + e < L) ? x[r][e] - blmean : 0.f;
-      if (wave_in) {
-        const float xi0 = (float)i0 - ficl;
+      if (wave_in && i0 + 3 >= P.tail.from && i0 <= P.tail.until) {
+        float lv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = i0 + e;
-          const bool in = (i >= P.tail.from) && (i <= P.tail.until);
           const float v = x[r][e];
-          if (in && v <= 0.f) tail_bad = 1;
-          winf_accum(tl, P.tail, i, xi0 + (float)e, logf(fmaxf(v, 1e-30f)));
+          if (i >= P.tail.from && i <= P.tail.until && v <= 0.f) tail_bad = 1;
+          lv[e] = logf(fmaxf(v, 1e-30f));
         }
+        winf_accum4(tl, P.tail, i0, (float)i0 - ficl, lv[0], lv[1], lv[2], lv[3]);
       }
       tot[r] = (x[r][0] + x[r][1]) + (x[r][2] + x[r][3]);
     }
@@ -758,8 +776,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     for (int r = 0; r < R; ++r) {
       const int i0 = 4 * (tid + NT * r);
       const float xi0 = (float)i0 - ficp;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) winf_accum(pz, P.tail, i0 + e, xi0 + (float)e, y[r][e]);
+      winf_accum4(pz, P.tail, i0, xi0, y[r][0], y[r][1], y[r][2], y[r][3]);
       tot[r] = (y[r][0] + y[r][1]) + (y[r][2] + y[r][3]);
       *reinterpret_cast<float4*>(&S.B0[i0]) = make_float4(y[r][0], y[r][1], y[r][2], y[r][3]);
     }
@@ -797,30 +814,55 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     const TrapDev t0 = P.t0, t0i = P.t0inv, f0 = P.fixed[0], f1 = P.fixed[1], f2 = P.fixed[2], fo = P.opt;
     const float thr0 = P.t0_thr;
     const bool inv_same = P.t0inv_same != 0;
-#pragma unroll 4
+    // one base register per shifted read; the row offset NT*m is an immediate
+    const float* yb = &S.B0[tid];
+    const float* tb = &S.B1[tid];
+    const float *t0a = tb + t0.n1, *t0b = tb + t0.n1 + t0.g, *t0c = tb + t0.flen;
+    const float *tia = tb + t0i.n1, *tib = tb + t0i.n1 + t0i.g, *tic = tb + t0i.flen;
+    const float *f0a = tb + f0.n1, *f0b = tb + f0.n1 + f0.g, *f0c = tb + f0.flen;
+    const float *f1a = tb + f1.n1, *f1b = tb + f1.n1 + f1.g, *f1c = tb + f1.flen;
+    const float *f2a = tb + f2.n1, *f2b = tb + f2.n1 + f2.g, *f2c = tb + f2.flen;
+    const float *foa = tb + fo.n1, *fob = tb + fo.n1 + fo.g, *foc = tb + fo.flen;
+    // rows entirely inside an output range need no per-lane masking (uniform test, scalar branch)
+    auto masked = [&](float o, int k, int m, int nout) { return (NT * (m + 1) <= nout) ? o : ((k < nout) ? o : -INFINITY); };
+#pragma unroll
     for (int m = 0; m < SP; ++m) {
       const int k = tid + NT * m;
       const int wb = (NT >> 5) * m + 2 * wave;
-      const float yv = (k < L) ? S.B0[k] : -INFINITY;
+      const float yv = masked(yb[NT * m], k, m, L);
       unsigned long long bq[7];
 #pragma unroll
       for (int q = 0; q < 5; ++q) bq[q] = __ballot(yv >= thr_tx[q]);
-      float o0 = -INFINITY;
-      if (k < nout_t0) o0 = trap_at(S.B1, k, t0);
+      const float Tk = tb[NT * m];
+      const float o0 = masked((t0c[NT * m] - t0b[NT * m]) * t0.inv2 - (t0a[NT * m] - Tk) * t0.inv1, k, m, nout_t0);
       bq[M_T0] = __ballot(o0 >= thr0);
       float o0i;
-      if (inv_same) o0i = (k < nout_t0) ? -o0 : -INFINITY;
-      else o0i = (k < nout_t0i) ? -trap_at(S.B1, k, t0i) : -INFINITY;
+      if (inv_same) o0i = masked(-o0, k, m, nout_t0);   // -(-inf) would be +inf: re-mask
+      else o0i = masked(-((tic[NT * m] - tib[NT * m]) * t0i.inv2 - (tia[NT * m] - Tk) * t0i.inv1), k, m, nout_t0i);
       bq[M_T0INV] = __ballot(o0i >= thr0);
       if (lane == 0) {
 #pragma unroll
         for (int q = 0; q < 7; ++q)
           *reinterpret_cast<unsigned long long*>(&S.bm[q * NWORDS + wb]) = bq[q];
       }
-      if (k < nout_f0) { float o = trap_at(S.B1, k, f0); mx0 = fmaxf(mx0, o); mn0 = fminf(mn0, o); }
-      if (k < nout_f1) { float o = trap_at(S.B1, k, f1); mx1 = fmaxf(mx1, o); }
-      if (k < nout_f2) { float o = trap_at(S.B1, k, f2); mx2 = fmaxf(mx2, o); mn2 = fminf(mn2, o); }
-      if (k < nout_opt) { float o = trap_at(S.B1, k, fo); if (o > bo_v) { bo_v = o; bo_i = k; } }
+      if (NT * m < nout_f0) {
+        const float o = (f0c[NT * m] - f0b[NT * m]) * f0.inv2 - (f0a[NT * m] - Tk) * f0.inv1;
+        mx0 = fmaxf(mx0, masked(o, k, m, nout_f0));
+        mn0 = fminf(mn0, -masked(-o, k, m, nout_f0));
+      }
+      if (NT * m < nout_f1) {
+        const float o = (f1c[NT * m] - f1b[NT * m]) * f1.inv2 - (f1a[NT * m] - Tk) * f1.inv1;
+        mx1 = fmaxf(mx1, masked(o, k, m, nout_f1));
+      }
+      if (NT * m < nout_f2) {
+        const float o = (f2c[NT * m] - f2b[NT * m]) * f2.inv2 - (f2a[NT * m] - Tk) * f2.inv1;
+        mx2 = fmaxf(mx2, masked(o, k, m, nout_f2));
+        mn2 = fminf(mn2, -masked(-o, k, m, nout_f2));
+      }
+      if (NT * m < nout_opt) {
+        const float o = masked((foc[NT * m] - fob[NT * m]) * fo.inv2 - (foa[NT * m] - Tk) * fo.inv1, k, m, nout_opt);
+        if (o > bo_v) { bo_v = o; bo_i = k; }
+      }
     }
     mx0 = wave_max_all(mx0); mx1 = wave_max_all(mx1); mx2 = wave_max_all(mx2);
     mn0 = wave_min_all(mn0); mn2 = wave_min_all(mn2);
@@ -983,10 +1025,10 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
           const bool valid = k < ng;
           go[e] = valid ? g : -INFINITY;
           gmax = fmaxf(gmax, go[e]);
-          winf_accum(sgb, P.sgbl, valid ? k : -1, (float)k - ficg, g);
           if (valid && k >= P.cur_from[0] && k <= P.cur_until[0] && g > bv[0]) { bv[0] = g; bi[0] = k; }
         }
         *reinterpret_cast<float4*>(&S.B1[i0]) = make_float4(go[0], go[1], go[2], go[3]);
+        winf_accum4(sgb, P.sgbl, i0, (float)i0 - ficg, go[0], go[1], go[2], go[3]);  // sgbl.until <= ng-1: -inf never enters
         // SG(60 ns), SG(100 ns), plain derivative: only wave-rows that touch the current window
         const int wfirst = 4 * ((tid & ~63) + NT * r), wlast = wfirst + 255;
         if (wfirst <= whi && wlast >= wlo) {
@@ -1222,13 +1264,14 @@ pz_trap_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, flo
 
 template <int NT, int R>
 static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
-                                bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st) {
+                                bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid) {
   const size_t smem = Smem<NT, R>::bytes();
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_kernel<NT, R>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((icpc_kernel<NT, R>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, aux, out);
   e = hipGetLastError();
+  if (e == hipSuccess && mid) e = hipEventRecord(mid, st);  // stage boundary for per-kernel timing
   if (e != hipSuccess || stop_after_main) return e;
   const size_t smem_cz = Smem<NT, R, false>::bytes() + (size_t)cz_pad_floats * 4;
   auto launch_cz = [&](auto kern) -> hipError_t {
@@ -1244,13 +1287,13 @@ static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, f
   return launch_cz(&icpc_cz_kernel<NT, R, false, false, true>);
 }
 hipError_t launch_icpc(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
-                       bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st) {
+                       bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid) {
   switch (NT) {
-    case 64: return launch_icpc_t<64, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st);
-    case 128: return launch_icpc_t<128, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st);
-    case 256: return launch_icpc_t<256, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st);
-    case 512: return launch_icpc_t<512, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st);
-    case 1024: return launch_icpc_t<1024, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st);
+    case 64: return launch_icpc_t<64, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid);
+    case 128: return launch_icpc_t<128, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid);
+    case 256: return launch_icpc_t<256, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid);
+    case 512: return launch_icpc_t<512, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid);
+    case 1024: return launch_icpc_t<1024, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid);
     default: return hipErrorInvalidValue;
   }
 }

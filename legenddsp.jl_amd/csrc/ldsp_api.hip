@@ -17,7 +17,7 @@
 
 namespace ldsp {
 hipError_t launch_icpc(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
-                       bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st);
+                       bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid);
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 size_t icpc_smem_bytes(int NT);
 }  // namespace ldsp
@@ -80,6 +80,7 @@ int ldsp_ctx_create(int device, ldsp_ctx** out) {
   HIP_TRY(hipMalloc(&c->d_coef, sizeof(float) * LDSP_MAX_FIR_TAPS));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipEventCreate(&c->evm));
   *out = c;
   return LDSP_OK;
 }
@@ -89,7 +90,7 @@ int ldsp_ctx_destroy(ldsp_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_aux); (void)hipFree(c->d_coef);
-  (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+  (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); (void)hipEventDestroy(c->evm);
   (void)hipStreamDestroy(c->own_stream);
   delete c;
   return LDSP_OK;
@@ -133,6 +134,16 @@ int ldsp_ctx_last_kernel_ms(ldsp_ctx* c, float* ms) {
   float t = 0;
   HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
   *ms = t / (float)c->n_launches;
+  return LDSP_OK;
+}
+
+int ldsp_ctx_last_stage_ms(ldsp_ctx* c, int stage, float* ms) {
+  if (!c || !ms) return fail(LDSP_ERR_INVALID_ARG, "ctx/ms is NULL");
+  if (!c->timing || c->n_launches == 0) return fail(LDSP_ERR_INVALID_ARG, "timing not enabled or nothing launched");
+  if (stage < 0 || stage >= c->n_stages) return fail(LDSP_ERR_INVALID_ARG, "the last call had %d stage(s)", c->n_stages);
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  hipEvent_t a = stage == 0 ? c->ev0 : c->evm, b = (stage == 0 && c->n_stages > 1) ? c->evm : c->ev1;
+  HIP_TRY(hipEventElapsedTime(ms, a, b));
   return LDSP_OK;
 }
 
@@ -357,8 +368,9 @@ int ldsp_icpc_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_param
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->d_icpc, c->d_aux, od, c->icpc_host.cusp_mode == 0,
                       c->icpc_host.cz_shared != 0, c->dbg_stop != 0,
-                      ((std::max(c->icpc_host.cusp.Lf, c->icpc_host.zac.Lf) + 2 + 7) & ~3), c->stream));
-  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; }
+                      ((std::max(c->icpc_host.cusp.Lf, c->icpc_host.zac.Lf) + 2 + 7) & ~3), c->stream,
+                      c->timing ? c->evm : nullptr));
+  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = c->dbg_stop ? 1 : 2; }
   return LDSP_OK;
 }
 
@@ -372,7 +384,7 @@ int ldsp_icpc_pz_trap_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_ic
   if (rc) return rc;
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   HIP_TRY(launch_pz_trap(wf, n, c->icpc_host.NT, c->d_icpc, blmean, e_10410, c->stream));
-  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; }
+  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
   return LDSP_OK;
 }
 

@@ -33,8 +33,8 @@ struct ldsp_ctx {
   int dbg_stop = 0;
   // timing
   int timing = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int n_launches = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;  // evm: boundary between the two dsp_icpc kernels
+  int n_launches = 0, n_stages = 1;
 };
 
 // common argument checks of the per-trace entry points
