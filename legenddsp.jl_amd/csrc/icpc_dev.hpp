@@ -12,6 +12,7 @@ constexpr int SPT_HOST = 32;  // samples per thread of the trace kernels (== lds
 struct TrapDev {
   int32_t n1, g, n2, flen;  // navg, ngap, navg2, total length
   float inv1, inv2;         // 1/navg, 1/navg2
+  float rr, navg;           // inv2/inv1 and 1/inv1: the sweeps evaluate the trapezoid unscaled
 };
 
 // LSQ polynomial estimator (PolynomialDNI): yhat(u) = sum_i y[i0+i] * sum_j B[i][j] u^j,

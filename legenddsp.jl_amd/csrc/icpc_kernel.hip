@@ -196,6 +196,12 @@ __device__ __forceinline__ void win_publish(const WinAcc& a, double* wsum, int s
   }
 }
 template <int NW>
+__device__ __forceinline__ double win_collect1(const double* wsum, int slot) {  // one of a site's three sums
+  double a = 0;
+  for (int w = 0; w < NW; ++w) a += wsum[slot * NW + w];
+  return a;
+}
+template <int NW>
 __device__ __forceinline__ WinAcc win_collect(const double* wsum, int site) {
   WinAcc a = {0, 0, 0};
   for (int w = 0; w < NW; ++w) {
@@ -221,6 +227,35 @@ __device__ __forceinline__ float flt_eval_rare(const float* y, const float* c, i
   return flt_eval(y, c, np, f, k);
 }
 
+// The thread's R quads of one trace (S4 view).  FULL (L == 4*NT*R): R back-to-back 16-byte
+// loads with nothing between them; otherwise the address is clamped so that the loads are
+// still unconditional (all in flight together) and out-of-range quads are zeroed afterwards.
+template <int NT, int R, bool FULL>
+__device__ __forceinline__ void load_trace_s4(const float* __restrict__ w, int L, int tid, float (&x)[R][4]) {
+  if (FULL || (L & 3) == 0) {
+    float4 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = 4 * (tid + NT * r);
+      v[r] = *reinterpret_cast<const float4*>(w + (FULL ? i : max(min(i, L - 4), 0)));
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool ok = FULL || 4 * (tid + NT * r) < L;
+      x[r][0] = ok ? v[r].x : 0.f; x[r][1] = ok ? v[r].y : 0.f; x[r][2] = ok ? v[r].z : 0.f; x[r][3] = ok ? v[r].w : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = 4 * (tid + NT * r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[r][e] = w[min(i + e, L - 1)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[r][e] = (i + e < L) ? x[r][e] : 0.f;
+    }
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -234,14 +269,14 @@ __host__ __device__ inline int cz_pad(const IcpcDev& P) { return ((P.cusp.Lf > P
 
 // WANT_C / WANT_Z: which filters this launch evaluates.  Both = they share sigma / flat /
 // length / tau (one set of recursions); otherwise the host launches the kernel once per filter.
-template <int NT, int R, bool DIRECT, bool WANT_C, bool WANT_Z>
+template <int NT, int R, bool FULL, bool DIRECT, bool WANT_C, bool WANT_Z>
 __global__ void __launch_bounds__(NT, 4)
 icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, const float* __restrict__ aux, IcpcOutDev out) {
   using SM = Smem<NT, R, false>;
   constexpr int NW = SM::NW, SP = SM::SP, Lp = SM::Lp;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const IcpcDev& P = *Pp;
-  const int L = P.L, tid = threadIdx.x;
+  const int L = FULL ? Lp : P.L, tid = threadIdx.x;   // FULL: trace length == the tile, every bounds test folds
   const int lane = lane_id(), wave = wave_id();
   const int pad = cz_pad(P);
   SM S(smem_raw, pad);
@@ -256,20 +291,7 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
   ptx[1].fp = aux[4 * (size_t)blockIdx.x + 2];
 
   float y[R][4];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i = 4 * (tid + NT * r);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((L & 3) == 0) {
-      if (i < L) v = *reinterpret_cast<const float4*>(w + i);
-    } else {
-      if (i < L) v.x = w[i];
-      if (i + 1 < L) v.y = w[i + 1];
-      if (i + 2 < L) v.z = w[i + 2];
-      if (i + 3 < L) v.w = w[i + 3];
-    }
-    y[r][0] = v.x; y[r][1] = v.y; y[r][2] = v.z; y[r][3] = v.w;
-  }
+  load_trace_s4<NT, R, FULL>(w, L, tid, y);
   if (tid < (int)(sizeof(Slots) / 4)) reinterpret_cast<uint32_t*>(S.sl)[tid] = 0;  // only vi[] maxima are used here
   if (tid < 64) S.B1[Lp + tid] = 0.f;
   // y = (x - blmean) + c*cumsum(x - blmean), exactly as kernel 1 computes it
@@ -585,14 +607,14 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
   }
 }
 
-template <int NT, int R>
+template <int NT, int R, bool FULL>
 __global__ void __launch_bounds__(NT, 4)  // 4 waves/SIMD: <= 128 VGPRs, two 512-thread traces per CU
 icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float* __restrict__ aux, IcpcOutDev out) {
   using SM = Smem<NT, R>;
   constexpr int NW = SM::NW, SP = SM::SP, Lp = SM::Lp, NWORDS = SM::NWORDS;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const IcpcDev& P = *Pp;
-  const int L = P.L, tid = threadIdx.x;
+  const int L = FULL ? Lp : P.L, tid = threadIdx.x;   // FULL: trace length == the tile, every bounds test folds
   const int lane = lane_id(), wave = wave_id();
   SM S(smem_raw);
   const float* w = wf + (size_t)blockIdx.x * (size_t)L;
@@ -604,20 +626,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
 
   // ------------------------------------------------------------ phase 0: load
   float x[R][4];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i = 4 * (tid + NT * r);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((L & 3) == 0) {
-      if (i < L) v = *reinterpret_cast<const float4*>(w + i);
-    } else {
-      if (i < L) v.x = w[i];
-      if (i + 1 < L) v.y = w[i + 1];
-      if (i + 2 < L) v.z = w[i + 2];
-      if (i + 3 < L) v.w = w[i + 3];
-    }
-    x[r][0] = v.x; x[r][1] = v.y; x[r][2] = v.z; x[r][3] = v.w;
-  }
+  load_trace_s4<NT, R, FULL>(w, L, tid, x);
   if (tid < (int)(sizeof(Slots) / 4)) {  // reduction slots: identities
     uint32_t* raw = reinterpret_cast<uint32_t*>(S.sl);
     const int o = tid * 4;
@@ -631,7 +640,6 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
 
   // ------------------------------------------------- phase 1: raw-trace stats
   {
-    int n_low = 0, n_high = 0;
     float rmax = -INFINITY, rmin = INFINITY;
     WinAccF bl = {0, 0, 0, 0, 0, 0};
     const float fic = (float)P.bl.ic;
@@ -641,42 +649,54 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       const float xi0 = (float)i0 - fic;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int i = i0 + e;
-        const bool ok = i < L;
-        const float v = x[r][e];
-        n_low += (ok && v == P.sat_low);
-        n_high += (ok && v == P.sat_high);
-        rmax = fmaxf(rmax, ok ? v : -INFINITY);
-        rmin = fminf(rmin, ok ? v : INFINITY);
+        const bool ok = FULL || i0 + e < L;
+        rmax = fmaxf(rmax, ok ? x[r][e] : -INFINITY);
+        rmin = fminf(rmin, ok ? x[r][e] : INFINITY);
       }
       winf_accum4(bl, P.bl, i0, xi0, x[r][0], x[r][1], x[r][2], x[r][3]);
     }
     win_publish<NW>(winf_rebase(bl), S.wsum, 0);
-    n_low = wave_sum_all_i(n_low); n_high = wave_sum_all_i(n_high);
     rmax = wave_max_all(rmax); rmin = wave_min_all(rmin);
     __syncthreads();  // slots initialised
     if (lane == 0) {
-      if (n_low) atomicAdd(&S.sl->isum[IS_LOW], n_low);
-      if (n_high) atomicAdd(&S.sl->isum[IS_HIGH], n_high);
       atomicMax(&S.sl->fmx[FX_RAW], ford(rmax));
       atomicMin(&S.sl->fmn[FN_RAW], ford(rmin));
     }
   }
   __syncthreads();
-  const int n_low = S.sl->isum[IS_LOW], n_high = S.sl->isum[IS_HIGH];
-  float blmean;
-  {
-    float blsigma, blslope, bloffset;
-    win_finish(win_collect<NW>(S.wsum, 0), P.bl, P.t_first, P.dt, &blmean, &blsigma, &blslope, &bloffset);
-    put(C_blmean, blmean); put(C_blsigma, blsigma); put(C_blslope, blslope); put(C_bloffset, bloffset);
-    puti(C_n_sat_low, n_low); puti(C_n_sat_high, n_high);
+  // every thread needs the mean; sigma / slope / offset (double divisions, sqrt) only thread 0
+  const float blmean = (float)(win_collect1<NW>(S.wsum, 0) * P.bl.inv_n);
+  if (tid == 0) {
+    float m_, blsigma, blslope, bloffset;
+    win_finish(win_collect<NW>(S.wsum, 0), P.bl, P.t_first, P.dt, &m_, &blsigma, &blslope, &bloffset);
+    S.outv[C_blmean] = blmean; S.outv[C_blsigma] = blsigma; S.outv[C_blslope] = blslope; S.outv[C_bloffset] = bloffset;
   }
-  const float e_max = ford_inv(S.sl->fmx[FX_RAW]) - blmean;
-  put(C_e_max, e_max); put(C_e_min, ford_inv(S.sl->fmn[FN_RAW]) - blmean);
+  const float raw_max = ford_inv(S.sl->fmx[FX_RAW]), raw_min = ford_inv(S.sl->fmn[FN_RAW]);
+  const float e_max = raw_max - blmean;
+  put(C_e_max, e_max); put(C_e_min, raw_min - blmean);
 
   // saturation runs (reference src/saturation.jl:28-65): rare path, only when a
   // saturated sample exists.  Flags through LDS -> ballots -> thread 0/1 walk the words.
-  int cons_low = 0, cons_high = 0;
+  // A sample can only sit on a rail if the trace's extremes reach it: count (and look
+  // for runs) only then.
+  int n_low = 0, n_high = 0, cons_low = 0, cons_high = 0;
+  if (raw_min <= P.sat_low || raw_max >= P.sat_high) {  // block-uniform
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = FULL || 4 * (tid + NT * r) + e < L;
+        n_low += (ok && x[r][e] == P.sat_low);
+        n_high += (ok && x[r][e] == P.sat_high);
+      }
+    n_low = wave_sum_all_i(n_low); n_high = wave_sum_all_i(n_high);
+    if (lane == 0) {
+      if (n_low) atomicAdd(&S.sl->isum[IS_LOW], n_low);
+      if (n_high) atomicAdd(&S.sl->isum[IS_HIGH], n_high);
+    }
+    __syncthreads();
+    n_low = S.sl->isum[IS_LOW]; n_high = S.sl->isum[IS_HIGH];
+  }
   if (n_low > 0 || n_high > 0) {  // block-uniform
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -708,6 +728,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     cons_high = __float_as_int(S.misc[1]);
     __syncthreads();
   }
+  puti(C_n_sat_low, n_low); puti(C_n_sat_high, n_high);
   puti(C_n_sat_low_cons, cons_low); puti(C_n_sat_high_cons, cons_high);
   if (P.dbg_stop == 1) return;
 
@@ -744,14 +765,14 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     if (__ballot(tail_bad) != 0ull && lane == 0) atomicAdd(&S.sl->isum[IS_TAILBAD], 1);
     s4_exscan_sum<NT, R>(tot, s_off, part_buf(), nullptr);  // barrier inside: tail sums published too
   }
-  {
+  if (tid == 0) {
     float tail_mean = 0.f, tail_sigma = 0.f, tail_tau = 0.f;
     if (S.sl->isum[IS_TAILBAD] == 0) {
       float sl, of;
       win_finish(win_collect<NW>(S.wsum, 3), P.tail, P.t_first, P.dt, &tail_mean, &tail_sigma, &sl, &of);
       tail_tau = -1.f / sl;
     }
-    put(C_tail_tau, tail_tau); put(C_tail_mean, tail_mean); put(C_tail_sigma, tail_sigma);
+    S.outv[C_tail_tau] = tail_tau; S.outv[C_tail_mean] = tail_mean; S.outv[C_tail_sigma] = tail_sigma;
   }
   // InvCRFilter: y = x + c*cumsum(x)  (dsp_icpc.jl:119-120);  x[][] becomes y
 #pragma unroll
@@ -794,12 +815,14 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       *reinterpret_cast<float4*>(&S.B1[i0]) = t;
     }
     if (tid == 0) S.B1[Lp] = (float)tot_all;  // T[Lp] (= T[L] when L == Lp; y is 0 beyond L)
+    for (int i = tid; i < 7 * NWORDS / 4; i += NT)  // phase-3 mask words: only non-zero ballots are stored
+      reinterpret_cast<uint4*>(S.bm)[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
-  {
+  if (tid == 0) {
     float tailmean, tailsigma, tailslope, tailoffset;
     win_finish(win_collect<NW>(S.wsum, 6), P.tail, P.t_first, P.dt, &tailmean, &tailsigma, &tailslope, &tailoffset);
-    put(C_tailmean, tailmean); put(C_tailsigma, tailsigma); put(C_tailslope, tailslope); put(C_tailoffset, tailoffset);
+    S.outv[C_tailmean] = tailmean; S.outv[C_tailsigma] = tailsigma; S.outv[C_tailslope] = tailslope; S.outv[C_tailoffset] = tailoffset;
   }
   if (P.dbg_stop == 2) return;
 
@@ -812,57 +835,88 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     const int nout_f0 = L - P.fixed[0].flen + 1, nout_f1 = L - P.fixed[1].flen + 1,
               nout_f2 = L - P.fixed[2].flen + 1, nout_opt = L - P.opt.flen + 1;
     const TrapDev t0 = P.t0, t0i = P.t0inv, f0 = P.fixed[0], f1 = P.fixed[1], f2 = P.fixed[2], fo = P.opt;
-    const float thr0 = P.t0_thr;
     const bool inv_same = P.t0inv_same != 0;
-    // one base register per shifted read; the row offset NT*m is an immediate
-    const float* yb = &S.B0[tid];
+    // One base register per shifted read; the row offset NT*m is an immediate.  A trapezoid is
+    // evaluated unscaled, o' = (T[k+flen]-T[k+n1+g])*(inv2/inv1) - (T[k+n1]-T[k]) (two subtractions and
+    // one fma), thresholds are divided by inv1 and maxima multiplied by it after the sweep.
+    // Rows wholly inside an output range skip the per-lane range test (scalar branch on the row).
     const float* tb = &S.B1[tid];
-    const float *t0a = tb + t0.n1, *t0b = tb + t0.n1 + t0.g, *t0c = tb + t0.flen;
-    const float *tia = tb + t0i.n1, *tib = tb + t0i.n1 + t0i.g, *tic = tb + t0i.flen;
-    const float *f0a = tb + f0.n1, *f0b = tb + f0.n1 + f0.g, *f0c = tb + f0.flen;
-    const float *f1a = tb + f1.n1, *f1b = tb + f1.n1 + f1.g, *f1c = tb + f1.flen;
-    const float *f2a = tb + f2.n1, *f2b = tb + f2.n1 + f2.g, *f2c = tb + f2.flen;
-    const float *foa = tb + fo.n1, *fob = tb + fo.n1 + fo.g, *foc = tb + fo.flen;
-    // rows entirely inside an output range need no per-lane masking (uniform test, scalar branch)
-    auto masked = [&](float o, int k, int m, int nout) { return (NT * (m + 1) <= nout) ? o : ((k < nout) ? o : -INFINITY); };
+    auto traw = [&](const float* a, const float* b, const float* c, float rr, float Tk, int m) {
+      return fmaf(c[NT * m] - b[NT * m], rr, -(a[NT * m] - Tk));
+    };
+    // ---- sweep A: threshold bit-masks of y (5) and of the t0 trapezoid (2)
+    {
+      const float* yb = &S.B0[tid];
+      const float *t0a = tb + t0.n1, *t0b = tb + t0.n1 + t0.g, *t0c = tb + t0.flen;
+      const float *tia = tb + t0i.n1, *tib = tb + t0i.n1 + t0i.g, *tic = tb + t0i.flen;
+      const float rr0 = t0.rr, rri = t0i.rr;
+      const float thr0 = P.t0_thr * t0.navg, thr0i = -P.t0_thr * t0i.navg;
 #pragma unroll
-    for (int m = 0; m < SP; ++m) {
-      const int k = tid + NT * m;
-      const int wb = (NT >> 5) * m + 2 * wave;
-      const float yv = masked(yb[NT * m], k, m, L);
-      unsigned long long bq[7];
+      for (int m = 0; m < SP; ++m) {
+        const int k = tid + NT * m;
+        float yv = yb[NT * m];
+        if (!FULL && NT * (m + 1) > L) yv = (k < L) ? yv : -INFINITY;
+        unsigned long long bq[7];
 #pragma unroll
-      for (int q = 0; q < 5; ++q) bq[q] = __ballot(yv >= thr_tx[q]);
-      const float Tk = tb[NT * m];
-      const float o0 = masked((t0c[NT * m] - t0b[NT * m]) * t0.inv2 - (t0a[NT * m] - Tk) * t0.inv1, k, m, nout_t0);
-      bq[M_T0] = __ballot(o0 >= thr0);
-      float o0i;
-      if (inv_same) o0i = masked(-o0, k, m, nout_t0);   // -(-inf) would be +inf: re-mask
-      else o0i = masked(-((tic[NT * m] - tib[NT * m]) * t0i.inv2 - (tia[NT * m] - Tk) * t0i.inv1), k, m, nout_t0i);
-      bq[M_T0INV] = __ballot(o0i >= thr0);
-      if (lane == 0) {
+        for (int q = 0; q < 5; ++q) bq[q] = __ballot(yv >= thr_tx[q]);
+        const float Tk = tb[NT * m];
+        float o0 = NAN, o0i = NAN;   // NaN: both comparisons false for rows/lanes outside the output range
+        if (NT * (m + 1) <= nout_t0) o0 = traw(t0a, t0b, t0c, rr0, Tk, m);
+        else if (NT * m < nout_t0) { o0 = traw(t0a, t0b, t0c, rr0, Tk, m); o0 = (k < nout_t0) ? o0 : NAN; }
+        if (inv_same) o0i = o0;
+        else if (NT * (m + 1) <= nout_t0i) o0i = traw(tia, tib, tic, rri, Tk, m);
+        else if (NT * m < nout_t0i) { o0i = traw(tia, tib, tic, rri, Tk, m); o0i = (k < nout_t0i) ? o0i : NAN; }
+        bq[M_T0] = __ballot(o0 >= thr0);
+        bq[M_T0INV] = __ballot(o0i <= thr0i);   // -trap >= thr
+        // the mask words were zeroed in phase 2: all-zero ballots (most rows of the t0 masks, the
+        // baseline rows of the y masks) are not stored.  thr_tx ascends, so bq[0] covers bq[1..4].
+        if (lane == 0) {
+          const int wb = (NT >> 5) * m + 2 * wave;
+          if (bq[0] | (e_max <= 0.f ? ~0ull : 0ull)) {
 #pragma unroll
-        for (int q = 0; q < 7; ++q)
-          *reinterpret_cast<unsigned long long*>(&S.bm[q * NWORDS + wb]) = bq[q];
+            for (int q = 0; q < 5; ++q) *reinterpret_cast<unsigned long long*>(&S.bm[q * NWORDS + wb]) = bq[q];
+          }
+          if (bq[M_T0]) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0 * NWORDS + wb]) = bq[M_T0];
+          if (bq[M_T0INV]) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0INV * NWORDS + wb]) = bq[M_T0INV];
+        }
       }
-      if (NT * m < nout_f0) {
-        const float o = (f0c[NT * m] - f0b[NT * m]) * f0.inv2 - (f0a[NT * m] - Tk) * f0.inv1;
-        mx0 = fmaxf(mx0, masked(o, k, m, nout_f0));
-        mn0 = fminf(mn0, -masked(-o, k, m, nout_f0));
+    }
+    // ---- sweep B: extrema of the three fixed trapezoids and the arg-max of the optimised one
+    {
+      const float *f0a = tb + f0.n1, *f0b = tb + f0.n1 + f0.g, *f0c = tb + f0.flen;
+      const float *f1a = tb + f1.n1, *f1b = tb + f1.n1 + f1.g, *f1c = tb + f1.flen;
+      const float *f2a = tb + f2.n1, *f2b = tb + f2.n1 + f2.g, *f2c = tb + f2.flen;
+      const float *foa = tb + fo.n1, *fob = tb + fo.n1 + fo.g, *foc = tb + fo.flen;
+      const float rr0 = f0.rr, rr1 = f1.rr, rr2 = f2.rr, rro = fo.rr;
+#pragma unroll
+      for (int m = 0; m < SP; ++m) {
+        const int k = tid + NT * m;
+        const float Tk = tb[NT * m];
+        if (NT * (m + 1) <= nout_f0) {
+          const float o = traw(f0a, f0b, f0c, rr0, Tk, m);
+          mx0 = fmaxf(mx0, o); mn0 = fminf(mn0, o);
+        } else if (NT * m < nout_f0) {
+          const float o = traw(f0a, f0b, f0c, rr0, Tk, m);
+          mx0 = fmaxf(mx0, (k < nout_f0) ? o : -INFINITY); mn0 = fminf(mn0, (k < nout_f0) ? o : INFINITY);
+        }
+        if (NT * (m + 1) <= nout_f1) mx1 = fmaxf(mx1, traw(f1a, f1b, f1c, rr1, Tk, m));
+        else if (NT * m < nout_f1) { const float o = traw(f1a, f1b, f1c, rr1, Tk, m); mx1 = fmaxf(mx1, (k < nout_f1) ? o : -INFINITY); }
+        if (NT * (m + 1) <= nout_f2) {
+          const float o = traw(f2a, f2b, f2c, rr2, Tk, m);
+          mx2 = fmaxf(mx2, o); mn2 = fminf(mn2, o);
+        } else if (NT * m < nout_f2) {
+          const float o = traw(f2a, f2b, f2c, rr2, Tk, m);
+          mx2 = fmaxf(mx2, (k < nout_f2) ? o : -INFINITY); mn2 = fminf(mn2, (k < nout_f2) ? o : INFINITY);
+        }
+        if (NT * (m + 1) <= nout_opt) {
+          const float o = traw(foa, fob, foc, rro, Tk, m);
+          if (o > bo_v) { bo_v = o; bo_i = k; }
+        } else if (NT * m < nout_opt) {
+          const float o = traw(foa, fob, foc, rro, Tk, m);
+          if (k < nout_opt && o > bo_v) { bo_v = o; bo_i = k; }
+        }
       }
-      if (NT * m < nout_f1) {
-        const float o = (f1c[NT * m] - f1b[NT * m]) * f1.inv2 - (f1a[NT * m] - Tk) * f1.inv1;
-        mx1 = fmaxf(mx1, masked(o, k, m, nout_f1));
-      }
-      if (NT * m < nout_f2) {
-        const float o = (f2c[NT * m] - f2b[NT * m]) * f2.inv2 - (f2a[NT * m] - Tk) * f2.inv1;
-        mx2 = fmaxf(mx2, masked(o, k, m, nout_f2));
-        mn2 = fminf(mn2, -masked(-o, k, m, nout_f2));
-      }
-      if (NT * m < nout_opt) {
-        const float o = masked((foc[NT * m] - fob[NT * m]) * fo.inv2 - (foa[NT * m] - Tk) * fo.inv1, k, m, nout_opt);
-        if (o > bo_v) { bo_v = o; bo_i = k; }
-      }
+      mx0 *= f0.inv1; mn0 *= f0.inv1; mx1 *= f1.inv1; mx2 *= f2.inv1; mn2 *= f2.inv1; bo_v *= fo.inv1;
     }
     mx0 = wave_max_all(mx0); mx1 = wave_max_all(mx1); mx2 = wave_max_all(mx2);
     mn0 = wave_min_all(mn0); mn2 = wave_min_all(mn2);
@@ -1099,8 +1153,11 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   // in-trace pile-up threshold (dsp_routines.jl:75-77) and t50_current threshold (dsp_icpc.jl:192)
   float thr_intr, thr_sg50;
   {
-    float m_, sg_, sl_, of_;
-    win_finish(win_collect<NW>(S.wsum, 9), P.sgbl, 0.f, P.dt, &m_, &sg_, &sl_, &of_);
+    // sigma of the SG output over the baseline window: only the first two sums
+    const double m_ = win_collect1<NW>(S.wsum, 9) * P.sgbl.inv_n;
+    double var_ = win_collect1<NW>(S.wsum, 10) * P.sgbl.inv_n - m_ * m_;
+    if (var_ < 0) var_ = 0;
+    const float sg_ = (float)sqrt(var_);
     thr_intr = sg_ * P.intrace_nsigma;
     if (thr_intr == 0.f) thr_intr = 1.f;
     thr_sg50 = ford_inv(S.sl->fmx[FX_G]) * 0.5f;
@@ -1171,14 +1228,14 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
 // BASELINE config 2: blmean -> shift -> InvCR -> Trap(10us,4us) -> maximum
 // (reference src/dsp_icpc.jl:102-105,119-120,147-148).  Same load and scans as the
 // fused kernel, nothing else: 4L+8 algorithmic bytes per trace.
-template <int NT, int R>
+template <int NT, int R, bool FULL>
 __global__ void __launch_bounds__(NT)
 pz_trap_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float* __restrict__ o_blmean,
                float* __restrict__ o_e10410) {
   constexpr int NW = NT / 64, SP = 4 * R, Lp = NT * SP;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const IcpcDev& P = *Pp;
-  const int L = P.L, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  const int L = FULL ? Lp : P.L, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   float* B = reinterpret_cast<float*>(smem_raw);              // [Lp+64]  T
   double* part = reinterpret_cast<double*>(B + Lp + 64);      // [2][R*NW]
   double* wsum = part + 2 * R * NW;                           // [NW]
@@ -1186,19 +1243,10 @@ pz_trap_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, flo
   const float* w = wf + (size_t)blockIdx.x * (size_t)L;
   float x[R][4];
   double s1 = 0;
+  load_trace_s4<NT, R, FULL>(w, L, tid, x);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int i = 4 * (tid + NT * r);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((L & 3) == 0) {
-      if (i < L) v = *reinterpret_cast<const float4*>(w + i);
-    } else {
-      if (i < L) v.x = w[i];
-      if (i + 1 < L) v.y = w[i + 1];
-      if (i + 2 < L) v.z = w[i + 2];
-      if (i + 3 < L) v.w = w[i + 3];
-    }
-    x[r][0] = v.x; x[r][1] = v.y; x[r][2] = v.z; x[r][3] = v.w;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       if (i + e >= P.bl.from && i + e <= P.bl.until) s1 += (double)x[r][e];
@@ -1262,14 +1310,14 @@ pz_trap_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, flo
   }
 }
 
-template <int NT, int R>
+template <int NT, int R, bool FULL>
 static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
                                 bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid) {
   const size_t smem = Smem<NT, R>::bytes();
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_kernel<NT, R>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_kernel<NT, R, FULL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((icpc_kernel<NT, R>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, aux, out);
+  hipLaunchKernelGGL((icpc_kernel<NT, R, FULL>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, aux, out);
   e = hipGetLastError();
   if (e == hipSuccess && mid) e = hipEventRecord(mid, st);  // stage boundary for per-kernel timing
   if (e != hipSuccess || stop_after_main) return e;
@@ -1280,43 +1328,44 @@ static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, f
     hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(NT), smem_cz, st, wf, dP, (const float*)aux, out);
     return hipGetLastError();
   };
-  if (direct) return launch_cz(&icpc_cz_kernel<NT, R, true, true, true>);
-  if (cz_shared) return launch_cz(&icpc_cz_kernel<NT, R, false, true, true>);
-  e = launch_cz(&icpc_cz_kernel<NT, R, false, true, false>);
+  if (direct) return launch_cz(&icpc_cz_kernel<NT, R, FULL, true, true, true>);
+  if (cz_shared) return launch_cz(&icpc_cz_kernel<NT, R, FULL, false, true, true>);
+  e = launch_cz(&icpc_cz_kernel<NT, R, FULL, false, true, false>);
   if (e != hipSuccess) return e;
-  return launch_cz(&icpc_cz_kernel<NT, R, false, false, true>);
+  return launch_cz(&icpc_cz_kernel<NT, R, FULL, false, false, true>);
 }
-hipError_t launch_icpc(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
+// `full`: the trace length equals the tile (L == 16*NT), the specialisation without bounds tests
+hipError_t launch_icpc(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
                        bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid) {
+#define LDSP_CASE(N)                                                                                                        \
+  case N:                                                                                                                   \
+    return full ? launch_icpc_t<N, 4, true>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid) \
+                : launch_icpc_t<N, 4, false>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid);
   switch (NT) {
-    case 64: return launch_icpc_t<64, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid);
-    case 128: return launch_icpc_t<128, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid);
-    case 256: return launch_icpc_t<256, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid);
-    case 512: return launch_icpc_t<512, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid);
-    case 1024: return launch_icpc_t<1024, 4>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid);
+    LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
     default: return hipErrorInvalidValue;
   }
+#undef LDSP_CASE
 }
 
-template <int NT, int R>
+template <int NT, int R, bool FULL>
 static hipError_t launch_pz_t(const float* wf, int64_t n, const IcpcDev* dP, float* a, float* b, hipStream_t st) {
   constexpr int NW = NT / 64;
   const size_t smem = (size_t)(NT * 4 * R + 64) * 4 + 2 * R * NW * 8 + NW * 8 + NW * 4 + 16;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pz_trap_kernel<NT, R>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pz_trap_kernel<NT, R, FULL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((pz_trap_kernel<NT, R>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, a, b);
+  hipLaunchKernelGGL((pz_trap_kernel<NT, R, FULL>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, a, b);
   return hipGetLastError();
 }
-hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st) {
+hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st) {
+#define LDSP_CASE(N) \
+  case N: return full ? launch_pz_t<N, 4, true>(wf, n, dP, blmean, e10410, st) : launch_pz_t<N, 4, false>(wf, n, dP, blmean, e10410, st);
   switch (NT) {
-    case 64: return launch_pz_t<64, 4>(wf, n, dP, blmean, e10410, st);
-    case 128: return launch_pz_t<128, 4>(wf, n, dP, blmean, e10410, st);
-    case 256: return launch_pz_t<256, 4>(wf, n, dP, blmean, e10410, st);
-    case 512: return launch_pz_t<512, 4>(wf, n, dP, blmean, e10410, st);
-    case 1024: return launch_pz_t<1024, 4>(wf, n, dP, blmean, e10410, st);
+    LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
     default: return hipErrorInvalidValue;
   }
+#undef LDSP_CASE
 }
 
 size_t icpc_smem_bytes(int NT) { return 0; }

@@ -16,9 +16,9 @@
 #include "ldsp_ctx.hpp"
 
 namespace ldsp {
-hipError_t launch_icpc(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
+hipError_t launch_icpc(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
                        bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid);
-hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
+hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 size_t icpc_smem_bytes(int NT);
 }  // namespace ldsp
 
@@ -190,6 +190,7 @@ static TrapDev make_trap(const ldsp_trap& t) {
   TrapDev d;
   d.n1 = t.navg; d.g = t.ngap; d.n2 = t.navg2; d.flen = t.navg + t.ngap + t.navg2;
   d.inv1 = (float)(1.0 / t.navg); d.inv2 = (float)(1.0 / t.navg2);
+  d.rr = (float)((double)t.navg / (double)t.navg2); d.navg = (float)t.navg;
   return d;
 }
 static bool trap_ok(const ldsp_trap& t, int L) { return t.navg >= 1 && t.navg2 >= 1 && t.ngap >= 0 && t.navg + t.ngap + t.navg2 <= L; }
@@ -366,7 +367,7 @@ int ldsp_icpc_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_param
     c->aux_cap = n;
   }
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->d_icpc, c->d_aux, od, c->icpc_host.cusp_mode == 0,
+  HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->icpc_host.L == 16 * c->icpc_host.NT, c->d_icpc, c->d_aux, od, c->icpc_host.cusp_mode == 0,
                       c->icpc_host.cz_shared != 0, c->dbg_stop != 0,
                       ((std::max(c->icpc_host.cusp.Lf, c->icpc_host.zac.Lf) + 2 + 7) & ~3), c->stream,
                       c->timing ? c->evm : nullptr));
@@ -383,7 +384,7 @@ int ldsp_icpc_pz_trap_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_ic
   int rc = prepare_icpc(c, p);
   if (rc) return rc;
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  HIP_TRY(launch_pz_trap(wf, n, c->icpc_host.NT, c->d_icpc, blmean, e_10410, c->stream));
+  HIP_TRY(launch_pz_trap(wf, n, c->icpc_host.NT, c->icpc_host.L == 16 * c->icpc_host.NT, c->d_icpc, blmean, e_10410, c->stream));
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
   return LDSP_OK;
 }
