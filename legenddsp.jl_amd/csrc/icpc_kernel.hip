@@ -951,51 +951,44 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     // trap(-y) = -trap(y)  (dsp_icpc.jl:199-204)
     put(C_e_10410_inv, ford_inv(S.sl->fmx[FX_F0I])); put(C_e_313_inv, ford_inv(S.sl->fmx[FX_F2I]));
   }
-  // crossing positions (sample units, split int + frac); NaN -> 0 us (dsp_routines.jl:24,41)
-  Pos ptx[5];
-  float ttx[5];
-  const float p_t0time = -P.t_first / P.dt;  // sample position of t = 0
-#pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    if (S.sl->isum[IS_CNT0 + q] > 0) {
-      const int p = S.sl->imin[q];
-      const float yl = S.B0[p - 1], yh = S.B0[p];
-      ptx[q].ip = p - 1;
-      ptx[q].fp = (thr_tx[q] - yl) / (yh - yl);
-      ttx[q] = (P.t_first + P.dt * ((float)(p - 1) + ptx[q].fp)) * P.inv_unit_per_us;
-    } else {
-      ttx[q] = 0.f;
-      ptx[q].ip = 0; ptx[q].fp = p_t0time;
-      ptx[q] = pos_norm(ptx[q]);
-    }
-  }
+  // crossing positions (sample units, split int + frac); NaN -> 0 us (dsp_routines.jl:24,41).
+  // Seven interpolations, one per lane (lane q < 5: threshold q of y; 5: t0; 6: inverted t0),
+  // evaluated once per wave and handed out by readlane.
+  Pos ptx[3];   // [1] = t50, [2] = t80 (the only ones used further down); pt0
   Pos pt0;
-  float t0_us, t0inv_us;
   {
-    if (S.sl->isum[IS_CNT0 + M_T0] > 0) {
-      const int p = S.sl->imin[M_T0];
-      const float yl = trap_at(S.B1, p - 1, P.t0), yh = trap_at(S.B1, p, P.t0);
-      const float fr = (P.t0_thr - yl) / (yh - yl);
-      pt0.ip = p - 1 + (P.t0.flen - 1);  // trailing alignment (A1): back to input index space
-      pt0.fp = fr;
-      t0_us = (P.t_first + P.dt * ((float)pt0.ip + fr)) * P.inv_unit_per_us;
+    const int q = min(lane, 6);
+    const bool has = S.sl->isum[IS_CNT0 + q] > 0;
+    const int p = S.sl->imin[q];
+    const float frac = (q == 0) ? 0.1f : (q == 1) ? 0.5f : (q == 2) ? 0.8f : (q == 3) ? 0.9f : 0.99f;
+    const float thr = (q < 5) ? e_max * frac : P.t0_thr;   // same products as thr_tx[]
+    Pos pp; pp.ip = 0; pp.fp = -P.t_first / P.dt;            // sample position of t = 0
+    float us = 0.f;
+    if (has) {
+      float yl, yh; int base;
+      if (q < 5) {
+        yl = S.B0[p - 1]; yh = S.B0[p]; base = p - 1;
+      } else {
+        const bool inv = (q == 6);
+        const TrapDev& t = (inv && !P.t0inv_same) ? P.t0inv : P.t0;
+        yl = trap_at(S.B1, p - 1, t); yh = trap_at(S.B1, p, t);
+        if (inv) { yl = -yl; yh = -yh; }
+        base = p - 1 + (t.flen - 1);  // trailing alignment (A1): back to input index space
+      }
+      pp.ip = base; pp.fp = (thr - yl) / (yh - yl);
+      us = (P.t_first + P.dt * ((float)base + pp.fp)) * P.inv_unit_per_us;
     } else {
-      t0_us = 0.f;
-      pt0.ip = 0; pt0.fp = p_t0time;
-      pt0 = pos_norm(pt0);
+      pp = pos_norm(pp);
     }
-    if (S.sl->isum[IS_CNT0 + M_T0INV] > 0) {
-      const int p = S.sl->imin[M_T0INV];
-      const TrapDev& ti = P.t0inv_same ? P.t0 : P.t0inv;
-      const float yl = -trap_at(S.B1, p - 1, ti), yh = -trap_at(S.B1, p, ti);
-      const float fr = (P.t0_thr - yl) / (yh - yl);
-      t0inv_us = (P.t_first + P.dt * ((float)(p - 1 + ti.flen - 1) + fr)) * P.inv_unit_per_us;
-    } else {
-      t0inv_us = 0.f;
+    ptx[1].ip = __builtin_amdgcn_readlane(pp.ip, 1); ptx[1].fp = readlane_f(pp.fp, 1);
+    ptx[2].ip = __builtin_amdgcn_readlane(pp.ip, 2); ptx[2].fp = readlane_f(pp.fp, 2);
+    pt0.ip = __builtin_amdgcn_readlane(pp.ip, 5); pt0.fp = readlane_f(pp.fp, 5);
+    if (wave == 0) {
+      if (lane < 7) S.outv[lane == 0 ? C_t10 : lane == 1 ? C_t50 : lane == 2 ? C_t80 : lane == 3 ? C_t90 : lane == 4 ? C_t99 : lane == 5 ? C_t0 : C_t0_inv] = us;
+      const float t90 = readlane_f(us, 3), t0u = readlane_f(us, 5);
+      if (lane == 0) S.outv[C_drift_time] = (t90 - t0u) * P.unit_per_us;
     }
   }
-  put(C_t0, t0_us); put(C_t10, ttx[0]); put(C_t50, ttx[1]); put(C_t80, ttx[2]); put(C_t90, ttx[3]); put(C_t99, ttx[4]);
-  put(C_drift_time, (ttx[3] - t0_us) * P.unit_per_us); put(C_t0_inv, t0inv_us);
   if (P.dbg_stop == 4) return;
 
   // ------------------------------------------------ phase 3c: signal estimators
@@ -1032,10 +1025,11 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   // LS view: g[k] = sum_i c[i] y[k+i] (valid mode, trailing time axis).  The SG(sg_wl)
   // output is needed in full (pile-up scan, t50_current) and is parked in B1 (T lives on
   // in registers); SG(60ns), SG(100ns) and the plain derivative only in the current window.
-  float a_cur[4];
   const int ng = L - P.sg_npts[0] + 1;
   auto flt_at = [&](int f, int k) -> float { return flt_eval(S.B0, P.sg_c[f < 3 ? f : 0], P.sg_npts[f < 3 ? f : 0], f, k); };
   auto flt_rare = [&](int f, int k) -> float { return flt_eval_rare(S.B0, P.sg_c[f < 3 ? f : 0], P.sg_npts[f < 3 ? f : 0], f, k); };
+  static_assert(M_INTR == M_SG50 + 1, "mask order");
+  for (int i = tid; i < 2 * NWORDS / 4; i += NT) reinterpret_cast<uint4*>(S.bm + M_SG50 * NWORDS)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();  // phase 3c reads of T complete before B1 is recycled
   {
     float gmax = -INFINITY;
@@ -1069,22 +1063,30 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
           const float4 v = *reinterpret_cast<const float4*>(&S.B0[i0 + 4 + 4 * h]);  // past Lp this runs into B1: masked below
           win[4 + 4 * h] = v.x; win[5 + 4 * h] = v.y; win[6 + 4 * h] = v.z; win[7 + 4 * h] = v.w;
         }
+        const int wfirst = 4 * ((tid & ~63) + NT * r), wlast = wfirst + 255;  // this wave-row's sample range
         float go[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int k = i0 + e;
           float g = 0.f;
 #pragma unroll
           for (int i = 0; i < M; ++i) g = fmaf(c0[i], win[e + i], g);
-          const bool valid = k < ng;
-          go[e] = valid ? g : -INFINITY;
-          gmax = fmaxf(gmax, go[e]);
-          if (valid && k >= P.cur_from[0] && k <= P.cur_until[0] && g > bv[0]) { bv[0] = g; bi[0] = k; }
+          go[e] = g;
+        }
+        if (wlast >= ng) {   // only the wave-row holding the end of the output axis
+#pragma unroll
+          for (int e = 0; e < 4; ++e) go[e] = (i0 + e < ng) ? go[e] : -INFINITY;
+        }
+        gmax = fmaxf(gmax, fmaxf(fmaxf(go[0], go[1]), fmaxf(go[2], go[3])));
+        if (wfirst <= P.cur_until[0] && wlast >= P.cur_from[0]) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k = i0 + e;
+            if (k >= P.cur_from[0] && k <= P.cur_until[0] && go[e] > bv[0]) { bv[0] = go[e]; bi[0] = k; }
+          }
         }
         *reinterpret_cast<float4*>(&S.B1[i0]) = make_float4(go[0], go[1], go[2], go[3]);
         winf_accum4(sgb, P.sgbl, i0, (float)i0 - ficg, go[0], go[1], go[2], go[3]);  // sgbl.until <= ng-1: -inf never enters
         // SG(60 ns), SG(100 ns), plain derivative: only wave-rows that touch the current window
-        const int wfirst = 4 * ((tid & ~63) + NT * r), wlast = wfirst + 255;
         if (wfirst <= whi && wlast >= wlo) {
           const float ypv = (i0 > 0) ? S.B0[i0 - 1] : 0.f;
 #pragma unroll
@@ -1141,14 +1143,19 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    if (f == 2 && P.sg_same_02) { a_cur[2] = a_cur[0]; continue; }
+  // get_wvf_maximum (src/interpolation.jl:30-46): parabola through the three samples about the
+  // maximum if it is strictly interior.  Wave 0 only; lane 3f+d+1 evaluates filter f at i_f+d.
+  if (wave == 0) {
+    const int f = min(lane / 3, 3), d = lane - 3 * f - 1;
+    const int fs = (f == 2 && P.sg_same_02) ? 0 : f;
     float v; int i;
-    unpack_vi(S.sl->vi[VI_CUR0 + f], &v, &i);
-    // get_wvf_maximum (src/interpolation.jl:30-46): parabola if strictly interior
-    if (i > P.cur_from[f] && i < P.cur_until[f]) v = extrema3points(flt_rare(f, i - 1), flt_rare(f, i), flt_rare(f, i + 1));
-    a_cur[f] = v;
+    unpack_vi(S.sl->vi[VI_CUR0 + fs], &v, &i);
+    const bool interior = i > P.cur_from[fs] && i < P.cur_until[fs];
+    float ev = 0.f;
+    if (lane < 12 && interior) ev = flt_rare(fs, i + d);
+    const float em = __shfl(ev, 3 * f), e0 = __shfl(ev, 3 * f + 1), ep = __shfl(ev, 3 * f + 2);
+    if (interior) v = extrema3points(em, e0, ep);
+    if (lane < 12 && d == -1) S.outv[f == 0 ? C_a_sg : f == 1 ? C_a_60 : f == 2 ? C_a_100 : C_a_raw] = v;
   }
   // in-trace pile-up threshold (dsp_routines.jl:75-77) and t50_current threshold (dsp_icpc.jl:192)
   float thr_intr, thr_sg50;
@@ -1157,19 +1164,19 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     const double m_ = win_collect1<NW>(S.wsum, 9) * P.sgbl.inv_n;
     double var_ = win_collect1<NW>(S.wsum, 10) * P.sgbl.inv_n - m_ * m_;
     if (var_ < 0) var_ = 0;
-    const float sg_ = (float)sqrt(var_);
+    const float sg_ = sqrtf((float)var_);
     thr_intr = sg_ * P.intrace_nsigma;
     if (thr_intr == 0.f) thr_intr = 1.f;
     thr_sg50 = ford_inv(S.sl->fmx[FX_G]) * 0.5f;
   }
+#pragma unroll
   for (int m = 0; m < SP; ++m) {
-    const int k = tid + NT * m;
-    const float g = S.B1[k];  // the thread's own writes
+    const float g = S.B1[tid + NT * m];  // LS view of the SG output
     const unsigned long long b50 = __ballot(g >= thr_sg50), bin = __ballot(g >= thr_intr);
-    if (lane == 0) {
+    if (lane == 0) {  // words were zeroed before the SG pass: only non-zero ballots are stored
       const int wb = (NT >> 5) * m + 2 * wave;
-      *reinterpret_cast<unsigned long long*>(&S.bm[M_SG50 * NWORDS + wb]) = b50;
-      *reinterpret_cast<unsigned long long*>(&S.bm[M_INTR * NWORDS + wb]) = bin;
+      if (b50) *reinterpret_cast<unsigned long long*>(&S.bm[M_SG50 * NWORDS + wb]) = b50;
+      if (bin) *reinterpret_cast<unsigned long long*>(&S.bm[M_INTR * NWORDS + wb]) = bin;
     }
   }
   __syncthreads();
@@ -1181,31 +1188,29 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + M_INTR], c); atomicMax(&S.sl->imax[0], f); }
   }
   __syncthreads();
-  float t50cur_us, intr_x;
-  const int intr_n = S.sl->isum[IS_CNT0 + M_INTR];
-  {
-    const float tg_first = P.t_first + P.dt * (float)(P.sg_npts[0] - 1);  // trailing alignment (A1)
-    if (S.sl->isum[IS_CNT0 + M_SG50] > 0) {
-      const int p = S.sl->imin[M_SG50];
-      const float yl = flt_rare(0, p - 1), yh = flt_rare(0, p);
-      t50cur_us = (tg_first + P.dt * ((float)(p - 1) + (thr_sg50 - yl) / (yh - yl))) * P.inv_unit_per_us;
-    } else {
-      t50cur_us = 0.f;
-    }
-    if (intr_n > 0) {
-      // reversed index pos' = ng-1-e ; r[pos'-1] = g[e+1], r[pos'] = g[e]
-      const int e = S.sl->imax[0];
-      const int pr = ng - 1 - e;
-      const float yl = flt_rare(0, e + 1), yh = flt_rare(0, e);
-      const float xl = tg_first + P.dt * (float)(pr - 1);
-      const float xr_ = (thr_intr - yl) * P.dt / (yh - yl) + xl;
-      intr_x = (tg_first + P.dt * (float)(ng - 1)) - xr_;  // last(time) - x   (dsp_routines.jl:81)
-    } else {
-      intr_x = NAN;
+  // crossing interpolations: wave 0, lanes 0..3 evaluate the four SG samples they need
+  if (wave == 0) {
+    const int intr_n = S.sl->isum[IS_CNT0 + M_INTR];
+    const bool has50 = S.sl->isum[IS_CNT0 + M_SG50] > 0;
+    const int p = S.sl->imin[M_SG50], e = S.sl->imax[0];
+    const int at = (lane == 0) ? p - 1 : (lane == 1) ? p : (lane == 2) ? e + 1 : e;
+    float ev = 0.f;
+    if (lane < 4 && ((lane < 2) ? has50 : intr_n > 0)) ev = flt_rare(0, at);
+    const float yl5 = __shfl(ev, 0), yh5 = __shfl(ev, 1), yli = __shfl(ev, 2), yhi = __shfl(ev, 3);
+    if (lane == 0) {
+      const float tg_first = P.t_first + P.dt * (float)(P.sg_npts[0] - 1);  // trailing alignment (A1)
+      float t50cur_us = 0.f, intr_x = NAN;
+      if (has50) t50cur_us = (tg_first + P.dt * ((float)(p - 1) + (thr_sg50 - yl5) / (yh5 - yl5))) * P.inv_unit_per_us;
+      if (intr_n > 0) {
+        // reversed index pos' = ng-1-e ; r[pos'-1] = g[e+1], r[pos'] = g[e]
+        const int pr = ng - 1 - e;
+        const float xl = tg_first + P.dt * (float)(pr - 1);
+        const float xr_ = (thr_intr - yli) * P.dt / (yhi - yli) + xl;
+        intr_x = (tg_first + P.dt * (float)(ng - 1)) - xr_;  // last(time) - x   (dsp_routines.jl:81)
+      }
+      S.outv[C_t50_current] = t50cur_us; S.outv[C_inTrace_intersect] = intr_x; S.outv[C_inTrace_n] = __int_as_float(intr_n);
     }
   }
-  put(C_a_sg, a_cur[0]); put(C_a_60, a_cur[1]); put(C_a_100, a_cur[2]); put(C_a_raw, a_cur[3]);
-  put(C_t50_current, t50cur_us); put(C_inTrace_intersect, intr_x); puti(C_inTrace_n, intr_n);
   if (P.dbg_stop == 6) return;
 
   // CUSP / ZAC run in icpc_cz_kernel; hand over blmean and the t50 position
