@@ -90,11 +90,11 @@ __device__ __forceinline__ void s4_exscan_affine_bwd(const float (&b)[R], float 
                                                      float* part) {
   constexpr int NW = NT / 64;
   const int w = wave_id(), l = lane_id();
-  const float pw[6] = {qp4[1], qp4[2], qp4[4], qp4[8], qp4[16], qp4[32]};
-  const float fl = qp4[63 - l];
+  const AffinePow P = {qp4[1], qp4[2], qp4[4], qp4[8]};
+  const float fl = qp4[63 - l], frow = qp4[16 - (l & 15)], a16 = qp4[16];
   float inc[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) inc[r] = wave_incl_scan_affine_rev(b[r], pw);
+  for (int r = 0; r < R; ++r) inc[r] = wave_incl_scan_affine_rev(b[r], P, a16, frow);
   if (l == 0) {
 #pragma unroll
     for (int r = 0; r < R; ++r) part[r * NW + w] = inc[r];
@@ -109,8 +109,7 @@ __device__ __forceinline__ void s4_exscan_affine_bwd(const float (&b)[R], float 
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const float sw_in = readlane_f(pexc, NP - 1 - (r * NW + w));
-    float ex = __shfl_down(inc[r], 1, 64);
-    if (l == 63) ex = 0.f;
+    const float ex = wave_shl1(inc[r]);  // inclusive value of lane l+1 (0 for lane 63)
     s_in[r] = fmaf(fl, sw_in, ex);
   }
 }

@@ -35,14 +35,26 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// ---- fused DPP steps -------------------------------------------------------------
+// One VALU instruction per scan step: `v = op(dpp(v), v)` in place.  Without bound_ctrl a
+// lane whose DPP source is out of range (or whose row is masked off) is simply not
+// written, i.e. keeps v — the identity of every step below, so no `old` operand and no
+// separate v_mov_b32_dpp.  hipcc only fuses integer adds by itself (0.0 is not an fadd
+// identity for -0.0, fmax gets a canonicalisation), hence the asm.  s_nop 1 = the two
+// wait states a DPP read needs after a VALU write of the same VGPR; the first step of a
+// sequence uses s_nop 4 (covers a preceding v_cmpx write of EXEC as well).
+#define LDSP_DPP2(NOPS, OP, CTL, v) asm("s_nop " #NOPS "\n\t" OP " %0, %0, %0 " CTL : "+v"(v))
+#define LDSP_DPP3(NOPS, OP, CTL, v, p) asm("s_nop " #NOPS "\n\t" OP " %0, %0, %1 " CTL : "+v"(v) : "v"(p))
+#define LDSP_ROWS "row_mask:0xf bank_mask:0xf"
+
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ float wave_incl_scan_sum(float v) {
-  v += dpp_f<0x111>(0.f, v);
-  v += dpp_f<0x112>(0.f, v);
-  v += dpp_f<0x114>(0.f, v);
-  v += dpp_f<0x118>(0.f, v);
-  v += dpp_f<0x142, 0xa>(0.f, v);
-  v += dpp_f<0x143, 0xc>(0.f, v);
+  LDSP_DPP2(4, "v_add_f32_dpp", "row_shr:1 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_add_f32_dpp", "row_shr:2 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_add_f32_dpp", "row_shr:4 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_add_f32_dpp", "row_shr:8 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_add_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf", v);
+  LDSP_DPP2(1, "v_add_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf", v);
   return v;
 }
 __device__ __forceinline__ double wave_incl_scan_sum_f64(double v) {
@@ -68,23 +80,21 @@ __device__ __forceinline__ float wave_sum_all(float v) { return readlane_f(wave_
 __device__ __forceinline__ double wave_sum_all_f64(double v) { return readlane_d(wave_incl_scan_sum_f64(v), 63); }
 __device__ __forceinline__ int wave_sum_all_i(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_sum_i(v), 63); }
 __device__ __forceinline__ float wave_max_all(float v) {
-  const float ninf = -__builtin_inff();
-  v = fmaxf(v, dpp_f<0x111>(ninf, v));
-  v = fmaxf(v, dpp_f<0x112>(ninf, v));
-  v = fmaxf(v, dpp_f<0x114>(ninf, v));
-  v = fmaxf(v, dpp_f<0x118>(ninf, v));
-  v = fmaxf(v, dpp_f<0x142, 0xa>(ninf, v));
-  v = fmaxf(v, dpp_f<0x143, 0xc>(ninf, v));
+  LDSP_DPP2(4, "v_max_f32_dpp", "row_shr:1 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_max_f32_dpp", "row_shr:2 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_max_f32_dpp", "row_shr:4 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_max_f32_dpp", "row_shr:8 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_max_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf", v);
+  LDSP_DPP2(1, "v_max_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf", v);
   return readlane_f(v, 63);
 }
 __device__ __forceinline__ float wave_min_all(float v) {
-  const float pinf = __builtin_inff();
-  v = fminf(v, dpp_f<0x111>(pinf, v));
-  v = fminf(v, dpp_f<0x112>(pinf, v));
-  v = fminf(v, dpp_f<0x114>(pinf, v));
-  v = fminf(v, dpp_f<0x118>(pinf, v));
-  v = fminf(v, dpp_f<0x142, 0xa>(pinf, v));
-  v = fminf(v, dpp_f<0x143, 0xc>(pinf, v));
+  LDSP_DPP2(4, "v_min_f32_dpp", "row_shr:1 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_min_f32_dpp", "row_shr:2 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_min_f32_dpp", "row_shr:4 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_min_f32_dpp", "row_shr:8 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_min_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf", v);
+  LDSP_DPP2(1, "v_min_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf", v);
   return readlane_f(v, 63);
 }
 
@@ -95,25 +105,33 @@ __device__ __forceinline__ float wave_min_all(float v) {
 // row), f15 = a^((lane&15)+1), f31 = a^((lane&31)+1) (row-total broadcasts).
 struct AffinePow { float p1, p2, p4, p8; };
 __device__ __forceinline__ float wave_incl_scan_affine(float v, const AffinePow& P, float f15, float f31) {
-  v = fmaf(P.p1, dpp_f<0x111>(0.f, v), v);
-  v = fmaf(P.p2, dpp_f<0x112>(0.f, v), v);
-  v = fmaf(P.p4, dpp_f<0x114>(0.f, v), v);
-  v = fmaf(P.p8, dpp_f<0x118>(0.f, v), v);
-  v = fmaf(f15, dpp_f<0x142, 0xa>(0.f, v), v);
-  v = fmaf(f31, dpp_f<0x143, 0xc>(0.f, v), v);
+  const float p1 = P.p1, p2 = P.p2, p4 = P.p4, p8 = P.p8;  // VOP2 DPP wants the multiplier in a VGPR
+  LDSP_DPP3(4, "v_fmac_f32_dpp", "row_shr:1 " LDSP_ROWS, v, p1);   // v += a^1 * v[l-1]
+  LDSP_DPP3(1, "v_fmac_f32_dpp", "row_shr:2 " LDSP_ROWS, v, p2);
+  LDSP_DPP3(1, "v_fmac_f32_dpp", "row_shr:4 " LDSP_ROWS, v, p4);
+  LDSP_DPP3(1, "v_fmac_f32_dpp", "row_shr:8 " LDSP_ROWS, v, p8);
+  LDSP_DPP3(1, "v_fmac_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf", v, f15);
+  LDSP_DPP3(1, "v_fmac_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf", v, f31);
   return v;
 }
-// mirror image: s_l = v_l + a*s_{l+1}  (anti-causal), via ds_bpermute shuffles
-// pw[s] = a^(2^s), s = 0..5
-__device__ __forceinline__ float wave_incl_scan_affine_rev(float v, const float (&pw)[6]) {
-  const int l = threadIdx.x & 63;
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    const int o = 1 << s;
-    float t = __shfl_down(v, o, 64);
-    if (l + o < 64) v = fmaf(pw[s], t, v);
-  }
-  return v;
+// mirror image: s_l = v_l + a*s_{l+1}  (anti-causal).  In-row steps by row_shl; there is no
+// reverse row broadcast, so the three row heads go through SGPRs (readlane) and are folded
+// with a16 = a^16; frow = a^(16-(lane&15)) carries a lane to the head of the next row.
+__device__ __forceinline__ float wave_incl_scan_affine_rev(float v, const AffinePow& P, float a16, float frow) {
+  const float p1 = P.p1, p2 = P.p2, p4 = P.p4, p8 = P.p8;
+  LDSP_DPP3(4, "v_fmac_f32_dpp", "row_shl:1 " LDSP_ROWS, v, p1);   // v += a^1 * v[l+1]
+  LDSP_DPP3(1, "v_fmac_f32_dpp", "row_shl:2 " LDSP_ROWS, v, p2);
+  LDSP_DPP3(1, "v_fmac_f32_dpp", "row_shl:4 " LDSP_ROWS, v, p4);
+  LDSP_DPP3(1, "v_fmac_f32_dpp", "row_shl:8 " LDSP_ROWS, v, p8);
+  const float s1 = readlane_f(v, 16), s2 = readlane_f(v, 32), s3 = readlane_f(v, 48);
+  const float t2 = fmaf(a16, s3, s2), t1 = fmaf(a16, t2, s1);
+  const int row = (threadIdx.x & 63) >> 4;
+  const float sel = (row == 0) ? t1 : (row == 1) ? t2 : (row == 2) ? s3 : 0.f;
+  return fmaf(frow, sel, v);
+}
+// value of lane l+1 (0 for lane 63) / lane l-1 (0 for lane 0)
+__device__ __forceinline__ float wave_shl1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
 }  // namespace ldsp
