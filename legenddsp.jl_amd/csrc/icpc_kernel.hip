@@ -123,60 +123,48 @@ __device__ __forceinline__ float estimate(const EstDev& E, Pos p, int nsig, F ge
   return wave_sum_all(v);
 }
 
-// Window statistics (signalstats / tailstats sums).  Per thread the sums run in
-// float about a local pivot p (any value close to the thread's samples, which keeps
-// the squares small), branch-free; they are re-based to absolute double sums once per
-// thread and combined across threads in double in a fixed order.
-struct WinAcc {   // absolute sums over the window: sum y, sum y^2, sum xi*y  (xi = i - ic)
+// Window statistics (signalstats / tailstats sums).  All threads of a trace sum
+// d = v - pivot about ONE block-uniform pivot (a sample of the window itself, so |d| is
+// the spread of the window, not its level): float partial sums per thread and per wave
+// (fused DPP adds), the <= 16 wave partials are combined in double in a fixed order and the
+// pivot is added back in double.  Mathematically the oracle's  sum(Y^2)/n - mean^2.
+struct WinAcc {   // sums over the window: sum d, sum d^2, sum xi*d  (xi = i - ic, d = v - pivot)
   double s1, s2, s3;
 };
-struct WinAccF {  // float partials about the pivot p = the thread's first in-window sample
-  float n, s1, s2, sx, sxi, p;
+struct WinAccF {
+  float s1, s2, sx;
 };
-__device__ __forceinline__ void winf_accum(WinAccF& a, const WinDev& w, int i, float xi, float v) {
+__device__ __forceinline__ void winf_accum(WinAccF& a, const WinDev& w, int i, float xi, float pivot, float v) {
   const bool in = (i >= w.from) && (i <= w.until);
-  if (in && a.n == 0.f) a.p = v;
-  const float vm = in ? v - a.p : 0.f, xm = in ? xi : 0.f;
-  a.n += in ? 1.f : 0.f;
-  a.s1 += vm;
-  a.s2 = fmaf(vm, vm, a.s2);
-  a.sx = fmaf(xm, vm, a.sx);
-  a.sxi += xm;
+  const float d = in ? v - pivot : 0.f;
+  a.s1 += d;
+  a.s2 = fmaf(d, d, a.s2);
+  a.sx = fmaf(xi, d, a.sx);
 }
-// four consecutive samples i0..i0+3 at once; rows outside the window cost one test
-__device__ __forceinline__ void winf_accum4(WinAccF& a, const WinDev& w, int i0, float xi0, float v0, float v1, float v2, float v3) {
-  const int lo = max(w.from - i0, 0), hi = min(w.until - i0, 3);  // in-window e in [lo, hi]
-  if (lo > hi) return;
-  if (a.n == 0.f) a.p = (lo == 0) ? v0 : (lo == 1) ? v1 : (lo == 2) ? v2 : v3;
-  const float v[4] = {v0, v1, v2, v3};
+// four consecutive samples i0..i0+3 at once; quads outside the window cost one test,
+// quads wholly inside run without masks
+__device__ __forceinline__ void winf_accum4(WinAccF& a, const WinDev& w, int i0, float xi0, float pivot, float v0, float v1,
+                                            float v2, float v3) {
+  const int lo = w.from - i0, hi = w.until - i0;  // in-window e in [lo, hi]
+  if (lo > 3 || hi < 0) return;
+  float d[4] = {v0 - pivot, v1 - pivot, v2 - pivot, v3 - pivot};
+  if (lo > 0 || hi < 3) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float m = (e >= lo && e <= hi) ? 1.f : 0.f;
-    const float d = (v[e] - a.p) * m;
-    const float xm = (xi0 + (float)e) * m;
-    a.n += m;
-    a.s1 += d;
-    a.s2 = fmaf(d, d, a.s2);
-    a.sx = fmaf(xm, d, a.sx);
-    a.sxi += xm;
+    for (int e = 0; e < 4; ++e) d[e] = (e >= lo && e <= hi) ? d[e] : 0.f;
   }
-}
-__device__ __forceinline__ WinAcc winf_rebase(const WinAccF& a) {
-  const double p = (double)a.p, n = (double)a.n, s1 = (double)a.s1;
-  WinAcc r;
-  r.s1 = s1 + n * p;
-  r.s2 = (double)a.s2 + 2.0 * p * s1 + n * p * p;
-  r.s3 = (double)a.sx + p * (double)a.sxi;
-  return r;
+  a.s1 += (d[0] + d[1]) + (d[2] + d[3]);
+  a.s2 = fmaf(d[0], d[0], fmaf(d[1], d[1], fmaf(d[2], d[2], fmaf(d[3], d[3], a.s2))));
+  // sum (xi0+e) d_e = xi0 * sum d + (d1 + 2 d2 + 3 d3)
+  a.sx = fmaf(xi0, (d[0] + d[1]) + (d[2] + d[3]), a.sx + fmaf(3.f, d[3], fmaf(2.f, d[2], d[1])));
 }
 // (mean, sigma, slope per time unit, offset) from window sums — the arithmetic of
 // signalstats (RadiationDetectorDSP; restated in oracle/ldsp_oracle.c:orc_signalstats)
-__device__ __forceinline__ void win_finish(const WinAcc& a, const WinDev& w, float t_first, float dt, float* mean,
+__device__ __forceinline__ void win_finish(const WinAcc& a, const WinDev& w, float pivot, float t_first, float dt, float* mean,
                                            float* sigma, float* slope, float* offset) {
-  double m = a.s1 * w.inv_n;
-  double var = a.s2 * w.inv_n - m * m;
+  const double md = a.s1 * w.inv_n, m = (double)pivot + md;
+  double var = a.s2 * w.inv_n - md * md;
   if (var < 0) var = 0;
-  double cov = a.s3 * w.inv_n;  // mean of xi is 0
+  double cov = a.s3 * w.inv_n;  // mean of xi is 0, so the pivot drops out
   double sl_t = cov / w.var_i / (double)dt;
   double mean_x = (double)t_first + w.ic * (double)dt;
   *mean = (float)m;
@@ -186,13 +174,13 @@ __device__ __forceinline__ void win_finish(const WinAcc& a, const WinDev& w, flo
 }
 // per-wave partials of a window accumulator -> wsum[site..site+2][wave]
 template <int NW>
-__device__ __forceinline__ void win_publish(const WinAcc& a, double* wsum, int site) {
-  double s1 = wave_incl_scan_sum_f64(a.s1), s2 = wave_incl_scan_sum_f64(a.s2), s3 = wave_incl_scan_sum_f64(a.s3);
+__device__ __forceinline__ void win_publish(const WinAccF& a, double* wsum, int site) {
+  const float s1 = wave_incl_scan_sum(a.s1), s2 = wave_incl_scan_sum(a.s2), s3 = wave_incl_scan_sum(a.sx);
   if (lane_id() == 63) {
     const int w = wave_id();
-    wsum[(site + 0) * NW + w] = s1;
-    wsum[(site + 1) * NW + w] = s2;
-    wsum[(site + 2) * NW + w] = s3;
+    wsum[(site + 0) * NW + w] = (double)s1;
+    wsum[(site + 1) * NW + w] = (double)s2;
+    wsum[(site + 2) * NW + w] = (double)s3;
   }
 }
 template <int NW>
@@ -639,9 +627,10 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   if (tid < 64) S.B1[Lp + tid] = 0.f;
 
   // ------------------------------------------------- phase 1: raw-trace stats
+  const float pv_bl = w[P.bl.from];  // pivot of the baseline sums: the window's first sample (uniform scalar load)
   {
     float rmax = -INFINITY, rmin = INFINITY;
-    WinAccF bl = {0, 0, 0, 0, 0, 0};
+    WinAccF bl = {0, 0, 0};
     const float fic = (float)P.bl.ic;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -653,9 +642,9 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
         rmax = fmaxf(rmax, ok ? x[r][e] : -INFINITY);
         rmin = fminf(rmin, ok ? x[r][e] : INFINITY);
       }
-      winf_accum4(bl, P.bl, i0, xi0, x[r][0], x[r][1], x[r][2], x[r][3]);
+      winf_accum4(bl, P.bl, i0, xi0, pv_bl, x[r][0], x[r][1], x[r][2], x[r][3]);
     }
-    win_publish<NW>(winf_rebase(bl), S.wsum, 0);
+    win_publish<NW>(bl, S.wsum, 0);
     rmax = wave_max_all(rmax); rmin = wave_min_all(rmin);
     __syncthreads();  // slots initialised
     if (lane == 0) {
@@ -665,10 +654,10 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   }
   __syncthreads();
   // every thread needs the mean; sigma / slope / offset (double divisions, sqrt) only thread 0
-  const float blmean = (float)(win_collect1<NW>(S.wsum, 0) * P.bl.inv_n);
+  const float blmean = (float)((double)pv_bl + win_collect1<NW>(S.wsum, 0) * P.bl.inv_n);
   if (tid == 0) {
     float m_, blsigma, blslope, bloffset;
-    win_finish(win_collect<NW>(S.wsum, 0), P.bl, P.t_first, P.dt, &m_, &blsigma, &blslope, &bloffset);
+    win_finish(win_collect<NW>(S.wsum, 0), P.bl, pv_bl, P.t_first, P.dt, &m_, &blsigma, &blslope, &bloffset);
     S.outv[C_blmean] = blmean; S.outv[C_blsigma] = blsigma; S.outv[C_blslope] = blslope; S.outv[C_bloffset] = bloffset;
   }
   const float raw_max = ford_inv(S.sl->fmx[FX_RAW]), raw_min = ford_inv(S.sl->fmn[FN_RAW]);
@@ -735,8 +724,9 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   // shift_waveform(-blmean) (dsp_icpc.jl:105); tailstats on the shifted trace
   // (src/tailstats.jl:22-72); cumsum for the pole-zero correction
   double s_off[R];
+  const float pv_tl = __logf(fmaxf(w[P.tail.from] - blmean, 1e-30f));  // pivot of the log sums: the window's first sample
   {
-    WinAccF tl = {0, 0, 0, 0, 0, 0};
+    WinAccF tl = {0, 0, 0};
     int tail_bad = 0;
     float tot[R];
     const float ficl = (float)P.tail.ic;
@@ -755,13 +745,13 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
           const int i = i0 + e;
           const float v = x[r][e];
           if (i >= P.tail.from && i <= P.tail.until && v <= 0.f) tail_bad = 1;
-          lv[e] = logf(fmaxf(v, 1e-30f));
+          lv[e] = __logf(fmaxf(v, 1e-30f));
         }
-        winf_accum4(tl, P.tail, i0, (float)i0 - ficl, lv[0], lv[1], lv[2], lv[3]);
+        winf_accum4(tl, P.tail, i0, (float)i0 - ficl, pv_tl, lv[0], lv[1], lv[2], lv[3]);
       }
       tot[r] = (x[r][0] + x[r][1]) + (x[r][2] + x[r][3]);
     }
-    win_publish<NW>(winf_rebase(tl), S.wsum, 3);
+    win_publish<NW>(tl, S.wsum, 3);
     if (__ballot(tail_bad) != 0ull && lane == 0) atomicAdd(&S.sl->isum[IS_TAILBAD], 1);
     s4_exscan_sum<NT, R>(tot, s_off, part_buf(), nullptr);  // barrier inside: tail sums published too
   }
@@ -769,7 +759,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     float tail_mean = 0.f, tail_sigma = 0.f, tail_tau = 0.f;
     if (S.sl->isum[IS_TAILBAD] == 0) {
       float sl, of;
-      win_finish(win_collect<NW>(S.wsum, 3), P.tail, P.t_first, P.dt, &tail_mean, &tail_sigma, &sl, &of);
+      win_finish(win_collect<NW>(S.wsum, 3), P.tail, pv_tl, P.t_first, P.dt, &tail_mean, &tail_sigma, &sl, &of);
       tail_tau = -1.f / sl;
     }
     S.outv[C_tail_tau] = tail_tau; S.outv[C_tail_mean] = tail_mean; S.outv[C_tail_sigma] = tail_sigma;
@@ -789,24 +779,25 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   auto& y = x;
 
   // ------------------------------------------------- phase 2: T = prefix sum of y
+  float pv_pz;
   {
-    WinAccF pz = {0, 0, 0, 0, 0, 0};
-    const float ficp = (float)P.tail.ic;
     float tot[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i0 = 4 * (tid + NT * r);
-      const float xi0 = (float)i0 - ficp;
-      winf_accum4(pz, P.tail, i0, xi0, y[r][0], y[r][1], y[r][2], y[r][3]);
       tot[r] = (y[r][0] + y[r][1]) + (y[r][2] + y[r][3]);
       *reinterpret_cast<float4*>(&S.B0[i0]) = make_float4(y[r][0], y[r][1], y[r][2], y[r][3]);
     }
-    win_publish<NW>(winf_rebase(pz), S.wsum, 6);
     double t_off[R], tot_all;
-    s4_exscan_sum<NT, R>(tot, t_off, part_buf(), &tot_all);
+    s4_exscan_sum<NT, R>(tot, t_off, part_buf(), &tot_all);   // barrier inside: B0 = y is visible
+    // signalstats of the pole-zero corrected tail (dsp_icpc.jl:122), pivot = its first sample
+    WinAccF pz = {0, 0, 0};
+    pv_pz = S.B0[P.tail.from];
+    const float ficp = (float)P.tail.ic;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i0 = 4 * (tid + NT * r);
+      winf_accum4(pz, P.tail, i0, (float)i0 - ficp, pv_pz, y[r][0], y[r][1], y[r][2], y[r][3]);
       double run = t_off[r];
       float4 t;
       float* pt = &t.x;
@@ -814,6 +805,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       for (int e = 0; e < 4; ++e) { pt[e] = (float)run; run += (double)y[r][e]; }
       *reinterpret_cast<float4*>(&S.B1[i0]) = t;
     }
+    win_publish<NW>(pz, S.wsum, 6);
     if (tid == 0) S.B1[Lp] = (float)tot_all;  // T[Lp] (= T[L] when L == Lp; y is 0 beyond L)
     for (int i = tid; i < 7 * NWORDS / 4; i += NT)  // phase-3 mask words: only non-zero ballots are stored
       reinterpret_cast<uint4*>(S.bm)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -821,7 +813,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   __syncthreads();
   if (tid == 0) {
     float tailmean, tailsigma, tailslope, tailoffset;
-    win_finish(win_collect<NW>(S.wsum, 6), P.tail, P.t_first, P.dt, &tailmean, &tailsigma, &tailslope, &tailoffset);
+    win_finish(win_collect<NW>(S.wsum, 6), P.tail, pv_pz, P.t_first, P.dt, &tailmean, &tailsigma, &tailslope, &tailoffset);
     S.outv[C_tailmean] = tailmean; S.outv[C_tailsigma] = tailsigma; S.outv[C_tailslope] = tailslope; S.outv[C_tailoffset] = tailoffset;
   }
   if (P.dbg_stop == 2) return;
@@ -1033,7 +1025,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   __syncthreads();  // phase 3c reads of T complete before B1 is recycled
   {
     float gmax = -INFINITY;
-    WinAccF sgb = {0, 0, 0, 0, 0, 0};
+    WinAccF sgb = {0, 0, 0};   // pivot 0: the SG derivative of a baseline has no level
     const float ficg = (float)P.sgbl.ic;
     float bv[4]; int bi[4];
 #pragma unroll
@@ -1085,7 +1077,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
           }
         }
         *reinterpret_cast<float4*>(&S.B1[i0]) = make_float4(go[0], go[1], go[2], go[3]);
-        winf_accum4(sgb, P.sgbl, i0, (float)i0 - ficg, go[0], go[1], go[2], go[3]);  // sgbl.until <= ng-1: -inf never enters
+        winf_accum4(sgb, P.sgbl, i0, (float)i0 - ficg, 0.f, go[0], go[1], go[2], go[3]);  // sgbl.until <= ng-1: -inf never enters
         // SG(60 ns), SG(100 ns), plain derivative: only wave-rows that touch the current window
         if (wfirst <= whi && wlast >= wlo) {
           const float ypv = (i0 > 0) ? S.B0[i0 - 1] : 0.f;
@@ -1117,7 +1109,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
         if (k < ng) {
           g0 = flt_at(0, k);
           gmax = fmaxf(gmax, g0);
-          winf_accum(sgb, P.sgbl, k, (float)k - ficg, g0);
+          winf_accum(sgb, P.sgbl, k, (float)k - ficg, 0.f, g0);
           if (k >= P.cur_from[0] && k <= P.cur_until[0] && g0 > bv[0]) { bv[0] = g0; bi[0] = k; }
         }
         S.B1[k] = g0;
@@ -1131,7 +1123,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
         }
       }
     }
-    win_publish<NW>(winf_rebase(sgb), S.wsum, 9);
+    win_publish<NW>(sgb, S.wsum, 9);
     gmax = wave_max_all(gmax);
     unsigned long long bk[4];
 #pragma unroll
@@ -1247,21 +1239,21 @@ pz_trap_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, flo
   float* fred = reinterpret_cast<float*>(wsum + NW);          // [NW]
   const float* w = wf + (size_t)blockIdx.x * (size_t)L;
   float x[R][4];
-  double s1 = 0;
   load_trace_s4<NT, R, FULL>(w, L, tid, x);
+  // baseline mean exactly as icpc_kernel forms it (same pivot, same summation order)
+  const float pv_bl = w[P.bl.from];
+  WinAccF bl = {0, 0, 0};
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int i = 4 * (tid + NT * r);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (i + e >= P.bl.from && i + e <= P.bl.until) s1 += (double)x[r][e];
+    const int i0 = 4 * (tid + NT * r);
+    winf_accum4(bl, P.bl, i0, 0.f, pv_bl, x[r][0], x[r][1], x[r][2], x[r][3]);
   }
-  s1 = wave_incl_scan_sum_f64(s1);
-  if (lane == 63) wsum[wave] = s1;
+  const float s1w = wave_incl_scan_sum(bl.s1);
+  if (lane == 63) wsum[wave] = (double)s1w;
   __syncthreads();
-  s1 = 0;
+  double s1 = 0;
   for (int ww = 0; ww < NW; ++ww) s1 += wsum[ww];
-  const float blmean = (float)(s1 * P.bl.inv_n);
+  const float blmean = (float)((double)pv_bl + s1 * P.bl.inv_n);
   float tot[R];
   double off[R];
 #pragma unroll
