@@ -280,7 +280,10 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
 
   float y[R][4];
   load_trace_s4<NT, R, FULL>(w, L, tid, y);
-  if (tid < (int)(sizeof(Slots) / 4)) reinterpret_cast<uint32_t*>(S.sl)[tid] = 0;  // only vi[] maxima are used here
+  if (tid < (int)(sizeof(Slots) / 4)) {  // fmx[0..1] (maxima: identity 0) and imin[0..1] (first index: identity INT_MAX) are used here
+    const int o = tid * 4;
+    reinterpret_cast<uint32_t*>(S.sl)[tid] = (o >= (int)offsetof(Slots, imin) && o < (int)offsetof(Slots, imax)) ? 0x7fffffffu : 0u;
+  }
   if (tid < 64) S.B1[Lp + tid] = 0.f;
   // y = (x - blmean) + c*cumsum(x - blmean), exactly as kernel 1 computes it
   {
@@ -322,15 +325,18 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
   }
   // extremestats + SignalEstimator on filter outputs held in the LS view
   // (acc[m] = out[tid + NT*m]); f = 0 CUSP, 1 ZAC.          dsp_icpc.jl:170-171,177-178
-  // Publishes per-wave partials; collect after the next barrier with finish_collect.
-  auto finish_publish = [&](int f, int Lf, const float (&acc)[SP]) {
+  // Three steps with a barrier between them: finish_publish (per-wave estimator partial, the
+  // maximum VALUE into an LDS slot), finish_locate (only threads holding that value look up its
+  // first index), finish_collect.
+  auto finish_publish = [&](int f, int Lf, const float (&acc)[SP], float* my_max) {
     const int nout = L - Lf + 1;
-    float bv = -INFINITY; int bi = 0x7fffffff;
+    float bv = -INFINITY;
 #pragma unroll
     for (int m = 0; m < SP; ++m) {
-      const int k = tid + NT * m;
-      if (k < nout && acc[m] > bv) { bv = acc[m]; bi = k; }
+      if (NT * (m + 1) <= nout) bv = fmaxf(bv, acc[m]);
+      else if (NT * m < nout) bv = fmaxf(bv, (tid + NT * m < nout) ? acc[m] : -INFINITY);
     }
+    *my_max = bv;
     // estimator window [i0, i0+npts): at most one output per thread (npts <= 64 <= NT)
     float part = 0.f;
     if (nout >= P.sig_est.npts) {
@@ -343,22 +349,35 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
       const float u = ((float)(p.ip - i0) + p.fp - P.sig_est.c) * P.sig_est.s_inv;
       const int ms = (i0 - tid + NT - 1) / NT;   // smallest m with tid + NT*m >= i0
       const int l = tid + NT * ms - i0;
-      float val = 0.f;
+      if (l >= 0 && l < P.sig_est.npts && ms >= 0 && ms < SP) {  // at most two waves get here
+        float val = 0.f;
 #pragma unroll
-      for (int m = 0; m < SP; ++m) val = (m == ms) ? acc[m] : val;
-      if (i0 >= tid - NT * SP && l >= 0 && l < P.sig_est.npts && ms >= 0 && ms < SP) part = est_weight(P.sig_est, l, u) * val;
+        for (int m = 0; m < SP; ++m) val = (m == ms) ? acc[m] : val;
+        part = est_weight(P.sig_est, l, u) * val;
+      }
     }
-    double ps = wave_incl_scan_sum_f64((double)part);
-    unsigned long long bk = wave_max_u64(pack_vi(bv, bi));
-    if (lane == 63) S.wsum[(12 + f) * NW + wave] = ps;
-    if (lane == 0) atomicMax(&S.sl->vi[VI_CUSP + f], bk);
+    const float ps = wave_incl_scan_sum(part);   // <= 64 terms, pairwise; waves are combined in double
+    const float bw = wave_max_all(bv);
+    if (lane == 63) S.wsum[(12 + f) * NW + wave] = (double)ps;
+    if (lane == 0) atomicMax(&S.sl->fmx[f], ford(bw));
+  };
+  auto finish_locate = [&](int f, int Lf, const float (&acc)[SP], float my_max) {
+    const int nout = L - Lf + 1;
+    const float vmax = ford_inv(S.sl->fmx[f]);
+    if (my_max == vmax) {   // findmax: first occurrence
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int m = SP - 1; m >= 0; --m)
+        if (tid + NT * m < nout && acc[m] == vmax) bi = tid + NT * m;
+      atomicMin(&S.sl->imin[f], bi);
+    }
   };
   auto finish_collect = [&](int f, int Lf) {
     const int nout = L - Lf + 1;
     double s = 0;
     for (int ww = 0; ww < NW; ++ww) s += S.wsum[(12 + f) * NW + ww];
-    float v; int i;
-    unpack_vi(S.sl->vi[VI_CUSP + f], &v, &i);
+    const float v = ford_inv(S.sl->fmx[f]);
+    const int i = S.sl->imin[f];
     put(f ? C_e_zac : C_e_cusp, (nout >= P.sig_est.npts) ? (float)s : NAN);
     put(f ? C_e_zac_max : C_e_cusp_max, v);
     put(f ? C_t_zac_max : C_t_cusp_max, P.t_first + P.dt * (float)(i + Lf - 1));
@@ -380,7 +399,10 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
         for (int m = 0; m < SP; ++m)
           if (tid + NT * m < nout) acc[m] = fmaf(hj, yp[NT * m], acc[m]);
       }
-      finish_publish(f, Lf, acc);
+      float my_max;
+      finish_publish(f, Lf, acc, &my_max);
+      __syncthreads();
+      finish_locate(f, Lf, acc, my_max);
     }
     __syncthreads();
     if (WANT_C) finish_collect(0, P.cusp.Lf);
@@ -540,31 +562,50 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
         if ((m & 1) == 1) asm volatile("" ::: "memory");
       }
       if (want_z) {
-        // ---- step A2 (S4): PRF = cumsum(cumsum(u)) in f64.  Last, when y / d / G / A registers are dead.
-        // (u was parked in B0 by step A1; B0 has not been touched since)
-        double O1[R], O2[R];
+        // ---- step A2 (S4): PRF = cumsum(cumsum(u)).  Last, when y / d / G / A registers are dead.
+        // (u was parked in B0 by step A1; B0 has not been touched since.)  Two levels: inside a
+        // wave-row (256 samples) the single and double running sums l1, l2 start from zero and
+        // stay in float (|l2| <= 2^15 |u|: its rounding is far below the float rounding of the
+        // result); the state entering each wave-row, (C1, C2), is carried in double:
+        //   c2[j] = C2 + (j+1)*C1 + l2[j],   C1' = C1 + l1[255],  C2' = C2 + 256*C1 + l2[255].
         {
-          double U[R], V[R];
+          float ex1[R], ex2[R];
+          double* pa = part_buf();
+          double* pb = part_buf();
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const float4 v = *reinterpret_cast<const float4*>(&S.B0[4 * (tid + NT * r)]);
-            const double u0 = (double)v.x, u1 = u0 + (double)v.y, u2 = u1 + (double)v.z, u3 = u2 + (double)v.w;
-            U[r] = u3; V[r] = (u0 + u1) + (u2 + u3);
+            const float p0 = v.x, p1 = p0 + v.y, p2 = p1 + v.z, p3 = p2 + v.w;
+            const float i1 = wave_incl_scan_sum(p3);
+            ex1[r] = i1 - p3;
+            const float wv = fmaf(4.f, ex1[r], (p0 + p1) + (p2 + p3));
+            const float i2 = wave_incl_scan_sum(wv);
+            ex2[r] = i2 - wv;
+            if (lane == 63) { pa[r * NW + wave] = (double)i1; pb[r * NW + wave] = (double)i2; }
           }
-          s4_exscan_sum<NT, R>(U, O1, part_buf(), nullptr);
+          __syncthreads();
+          // exclusive scans of the wave-row totals (R*NW <= 64 lanes), C2 with the 256*C1 term
+          const double t1 = (lane < R * NW) ? pa[lane] : 0.0;
+          const double c1x = wave_incl_scan_sum_f64(t1) - t1;
+          const double t2 = (lane < R * NW) ? pb[lane] + 256.0 * c1x : 0.0;
+          const double c2x = wave_incl_scan_sum_f64(t2) - t2;
+          const double mrho = -(double)ZZ.rho_sc;
+          const double jd0 = (double)(4 * lane + 1);
 #pragma unroll
-          for (int r = 0; r < R; ++r) V[r] += 4.0 * O1[r];   // W = 4*O1 + V
-          s4_exscan_sum<NT, R>(V, O2, part_buf(), nullptr);
-        }
-        const double mrho = -(double)ZZ.rho_sc;
+          for (int r = 0; r < R; ++r) {
+            const double C1 = readlane_d(c1x, r * NW + wave), C2 = readlane_d(c2x, r * NW + wave);
+            float4 v = *reinterpret_cast<const float4*>(&S.B0[4 * (tid + NT * r)]);  // u again (own chunk)
+            float* pv = &v.x;
+            double t = fma(C1, jd0, C2);   // C2 + (j+1)*C1 at the chunk's first sample
+            float l1 = ex1[r], l2 = ex2[r];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          float4 v = *reinterpret_cast<const float4*>(&S.B0[4 * (tid + NT * r)]);  // u again (own chunk)
-          float* pv = &v.x;
-          double c1 = O1[r], c2 = O2[r];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { c1 += (double)pv[e]; c2 += c1; pv[e] = (float)(mrho * c2); }
-          *reinterpret_cast<float4*>(&S.B0[4 * (tid + NT * r)]) = v;
+            for (int e = 0; e < 4; ++e) {
+              l1 += pv[e]; l2 += l1;
+              pv[e] = (float)(mrho * (t + (double)l2));
+              t += C1;
+            }
+            *reinterpret_cast<float4*>(&S.B0[4 * (tid + NT * r)]) = v;
+          }
         }
         __syncthreads();
 #pragma unroll
@@ -574,12 +615,16 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
           if ((m & 3) == 3) asm volatile("" ::: "memory");
         }
       }
-      if (want_c) finish_publish(0, Lf, ac);
+      float mxc = 0.f, mxz = 0.f;
       if (want_z) {
 #pragma unroll
         for (int m = 0; m < SP; ++m) dz[m] += ac[m];
-        finish_publish(1, Lf, dz);
       }
+      if (want_c) finish_publish(0, Lf, ac, &mxc);
+      if (want_z) finish_publish(1, Lf, dz, &mxz);
+      __syncthreads();
+      if (want_c) finish_locate(0, Lf, ac, mxc);
+      if (want_z) finish_locate(1, Lf, dz, mxz);
     }
     __syncthreads();
     if (WANT_C) finish_collect(0, P.cusp.Lf);
