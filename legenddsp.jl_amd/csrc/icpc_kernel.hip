@@ -62,6 +62,7 @@ enum { VI_OPT, VI_CUR0, VI_CUR1, VI_CUR2, VI_CUR3, VI_CUSP, VI_ZAC };
 enum { FX_RAW, FX_F0, FX_F1, FX_F2, FX_G, FX_F0I, FX_F2I };  // ..I: maxima of the inverted trapezoid outputs
 enum { FN_RAW };
 enum { IS_LOW, IS_HIGH, IS_TAILBAD, IS_CNT0 };
+constexpr int EST_TBL = LDSP_MAX_EST_PTS * (LDSP_MAX_EST_DEG + 1);
 constexpr int NSUM = 16;  // deterministic f64 sum sites x NW wave partials
 
 template <int NT, int R, bool MASKS = true>
@@ -76,9 +77,10 @@ struct Smem {
   float* ylast;   // [R*NW]    y at the last sample of each wave-row
   float* outv;    // [C_NCOLS]  output row, filled as results become available
   float* misc;    // [16]       small broadcasts
+  float* estB;    // [2][EST_TBL] LSQ basis tables of sig_est and int_est
   static constexpr size_t bytes() {
     return (size_t)(Lp + Lp + 64) * 4 + (MASKS ? (size_t)NMASK * NWORDS * 4 : 0) + 2 * R * NW * 8 + NSUM * NW * 8 + sizeof(Slots) +
-           R * NW * 4 + C_NCOLS * 4 + 16 * 4 + 64;
+           R * NW * 4 + C_NCOLS * 4 + 16 * 4 + 2 * EST_TBL * 4 + 64;
   }
   // pad: floats of zero-filled space in front of B1 (reads at small negative indices)
   __device__ explicit Smem(unsigned char* raw, int pad = 0) {
@@ -91,6 +93,7 @@ struct Smem {
     ylast = reinterpret_cast<float*>(sl + 1);
     outv = ylast + R * NW;
     misc = outv + C_NCOLS;
+    estB = misc + 16;
   }
 };
 
@@ -100,8 +103,10 @@ __device__ __forceinline__ float trap_at(const float* T, int k, const TrapDev& t
   return a * t.inv2 - b * t.inv1;
 }
 
-__device__ __forceinline__ float est_weight(const EstDev& E, int l, float u) {
-  const float* b = &E.B[l * (LDSP_MAX_EST_DEG + 1)];
+// Bt: the estimator's basis table staged in LDS at kernel start (a per-lane read from the
+// parameter block in global memory would put ~2 us of latency on the critical path)
+__device__ __forceinline__ float est_weight(const EstDev& E, const float* Bt, int l, float u) {
+  const float* b = &Bt[l * (LDSP_MAX_EST_DEG + 1)];
   float w = b[E.deg];
   for (int j = E.deg - 1; j >= 0; --j) w = fmaf(w, u, b[j]);
   return w;
@@ -110,7 +115,7 @@ __device__ __forceinline__ float est_weight(const EstDev& E, int l, float u) {
 // samples are produced by getval(i)); computed redundantly by every wave, lane l
 // handles window point l.  Assumption A3.
 template <typename F>
-__device__ __forceinline__ float estimate(const EstDev& E, Pos p, int nsig, F getval) {
+__device__ __forceinline__ float estimate(const EstDev& E, const float* Bt, Pos p, int nsig, F getval) {
   if (nsig < E.npts) return NAN;
   if (p.ip < 0) { p.ip = 0; p.fp = 0.f; }
   if (p.ip >= nsig - 1) { p.ip = nsig - 1; p.fp = 0.f; }
@@ -119,7 +124,7 @@ __device__ __forceinline__ float estimate(const EstDev& E, Pos p, int nsig, F ge
   float u = ((float)(p.ip - i0) + p.fp - E.c) * E.s_inv;
   const int l = lane_id();
   float v = 0.f;
-  if (l < E.npts) v = est_weight(E, l, u) * getval(i0 + l);
+  if (l < E.npts) v = est_weight(E, Bt, l, u) * getval(i0 + l);
   return wave_sum_all(v);
 }
 
@@ -280,6 +285,7 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
 
   float y[R][4];
   load_trace_s4<NT, R, FULL>(w, L, tid, y);
+  for (int i = tid; i < EST_TBL; i += NT) S.estB[i] = P.sig_est.B[i];
   if (tid < (int)(sizeof(Slots) / 4)) {  // fmx[0..1] (maxima: identity 0) and imin[0..1] (first index: identity INT_MAX) are used here
     const int o = tid * 4;
     reinterpret_cast<uint32_t*>(S.sl)[tid] = (o >= (int)offsetof(Slots, imin) && o < (int)offsetof(Slots, imax)) ? 0x7fffffffu : 0u;
@@ -312,6 +318,7 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
     }
   }
   __syncthreads();
+  if (P.dbg_stop == 11) return;  // profiling aid (tools/gpu_phase_time.py): stops 11..15 inside this kernel
   // y just before each of the thread's chunks (for d[i] = y[i] - a*y[i-1])
   float yprev[R];
 #pragma unroll
@@ -332,9 +339,10 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
     const int nout = L - Lf + 1;
     float bv = -INFINITY;
 #pragma unroll
-    for (int m = 0; m < SP; ++m) {
-      if (NT * (m + 1) <= nout) bv = fmaxf(bv, acc[m]);
-      else if (NT * m < nout) bv = fmaxf(bv, (tid + NT * m < nout) ? acc[m] : -INFINITY);
+    for (int m = 0; m < SP; m += 2) {
+      if (NT * (m + 2) <= nout) bv = vmax3(bv, acc[m], acc[m + 1]);   // both rows wholly inside
+      else if (NT * m < nout)
+        bv = vmax3(bv, (tid + NT * m < nout) ? acc[m] : -INFINITY, (tid + NT * (m + 1) < nout) ? acc[m + 1] : -INFINITY);
     }
     *my_max = bv;
     // estimator window [i0, i0+npts): at most one output per thread (npts <= 64 <= NT)
@@ -353,7 +361,7 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
         float val = 0.f;
 #pragma unroll
         for (int m = 0; m < SP; ++m) val = (m == ms) ? acc[m] : val;
-        part = est_weight(P.sig_est, l, u) * val;
+        part = est_weight(P.sig_est, S.estB, l, u) * val;
       }
     }
     const float ps = wave_incl_scan_sum(part);   // <= 64 terms, pairwise; waves are combined in double
@@ -479,6 +487,7 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
           for (int m = 0; m < SP; ++m) S.B0[tid + NT * m] = (tid + NT * m < L) ? u[m] : 0.f;
         }
       }
+      if (P.dbg_stop == 12) return;
       // ---- d[i] = (y[i]-y[i-1]) + eps*y[i-1] for 1 <= i < L, else 0   (S4)
       float d[R][4];
 #pragma unroll
@@ -526,6 +535,7 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
         }
         if ((m & 1) == 1) asm volatile("" ::: "memory");
       }
+      if (P.dbg_stop == 13) return;
       // ---- step C: anti-causal one-pole A -> B1, rise(+) and fall(-) exponentials
       {
         float al[R][4], b[R], s_in[R];
@@ -561,6 +571,7 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
         }
         if ((m & 1) == 1) asm volatile("" ::: "memory");
       }
+      if (P.dbg_stop == 14) return;
       if (want_z) {
         // ---- step A2 (S4): PRF = cumsum(cumsum(u)).  Last, when y / d / G / A registers are dead.
         // (u was parked in B0 by step A1; B0 has not been touched since.)  Two levels: inside a
@@ -615,6 +626,7 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
           if ((m & 3) == 3) asm volatile("" ::: "memory");
         }
       }
+      if (P.dbg_stop == 15) return;
       float mxc = 0.f, mxz = 0.f;
       if (want_z) {
 #pragma unroll
@@ -660,6 +672,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   // ------------------------------------------------------------ phase 0: load
   float x[R][4];
   load_trace_s4<NT, R, FULL>(w, L, tid, x);
+  for (int i = tid; i < 2 * EST_TBL; i += NT) S.estB[i] = (i < EST_TBL) ? P.sig_est.B[i] : P.int_est.B[i - EST_TBL];
   if (tid < (int)(sizeof(Slots) / 4)) {  // reduction slots: identities
     uint32_t* raw = reinterpret_cast<uint32_t*>(S.sl);
     const int o = tid * 4;
@@ -681,11 +694,16 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     for (int r = 0; r < R; ++r) {
       const int i0 = 4 * (tid + NT * r);
       const float xi0 = (float)i0 - fic;
+      if (FULL || i0 + 3 < L) {
+        rmax = vmax3(rmax, x[r][0], x[r][1]); rmax = vmax3(rmax, x[r][2], x[r][3]);
+        rmin = vmin3(rmin, x[r][0], x[r][1]); rmin = vmin3(rmin, x[r][2], x[r][3]);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool ok = FULL || i0 + e < L;
-        rmax = fmaxf(rmax, ok ? x[r][e] : -INFINITY);
-        rmin = fminf(rmin, ok ? x[r][e] : INFINITY);
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = i0 + e < L;
+          rmax = vmax(rmax, ok ? x[r][e] : -INFINITY);
+          rmin = vmin(rmin, ok ? x[r][e] : INFINITY);
+        }
       }
       winf_accum4(bl, P.bl, i0, xi0, pv_bl, x[r][0], x[r][1], x[r][2], x[r][3]);
     }
@@ -931,19 +949,19 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
         const float Tk = tb[NT * m];
         if (NT * (m + 1) <= nout_f0) {
           const float o = traw(f0a, f0b, f0c, rr0, Tk, m);
-          mx0 = fmaxf(mx0, o); mn0 = fminf(mn0, o);
+          mx0 = vmax(mx0, o); mn0 = vmin(mn0, o);
         } else if (NT * m < nout_f0) {
           const float o = traw(f0a, f0b, f0c, rr0, Tk, m);
-          mx0 = fmaxf(mx0, (k < nout_f0) ? o : -INFINITY); mn0 = fminf(mn0, (k < nout_f0) ? o : INFINITY);
+          mx0 = vmax(mx0, (k < nout_f0) ? o : -INFINITY); mn0 = vmin(mn0, (k < nout_f0) ? o : INFINITY);
         }
-        if (NT * (m + 1) <= nout_f1) mx1 = fmaxf(mx1, traw(f1a, f1b, f1c, rr1, Tk, m));
-        else if (NT * m < nout_f1) { const float o = traw(f1a, f1b, f1c, rr1, Tk, m); mx1 = fmaxf(mx1, (k < nout_f1) ? o : -INFINITY); }
+        if (NT * (m + 1) <= nout_f1) mx1 = vmax(mx1, traw(f1a, f1b, f1c, rr1, Tk, m));
+        else if (NT * m < nout_f1) { const float o = traw(f1a, f1b, f1c, rr1, Tk, m); mx1 = vmax(mx1, (k < nout_f1) ? o : -INFINITY); }
         if (NT * (m + 1) <= nout_f2) {
           const float o = traw(f2a, f2b, f2c, rr2, Tk, m);
-          mx2 = fmaxf(mx2, o); mn2 = fminf(mn2, o);
+          mx2 = vmax(mx2, o); mn2 = vmin(mn2, o);
         } else if (NT * m < nout_f2) {
           const float o = traw(f2a, f2b, f2c, rr2, Tk, m);
-          mx2 = fmaxf(mx2, (k < nout_f2) ? o : -INFINITY); mn2 = fminf(mn2, (k < nout_f2) ? o : INFINITY);
+          mx2 = vmax(mx2, (k < nout_f2) ? o : -INFINITY); mn2 = vmin(mn2, (k < nout_f2) ? o : INFINITY);
         }
         if (NT * (m + 1) <= nout_opt) {
           const float o = traw(foa, fob, foc, rro, Tk, m);
@@ -1039,13 +1057,13 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       if (e == 0) {
         Pos p = pos_add(ptx[1], P.trap_pickoff);
         p.ip -= (P.opt.flen - 1);
-        v = estimate(P.sig_est, p, L - P.opt.flen + 1, [&](int i) { return trap_at(S.B1, i, P.opt); });
+        v = estimate(P.sig_est, S.estB, p, L - P.opt.flen + 1, [&](int i) { return trap_at(S.B1, i, P.opt); });
       } else if (e <= 3) {  // get_qdrift(wvfs, t0, qdrift_int_length)   dsp_routines.jl:51-64
         const float d = (e == 1) ? 0.f : (e == 2 ? P.qdrift_d1 : P.qdrift_d2);
-        v = estimate(P.int_est, pos_add(pt0, d), L, I);
+        v = estimate(P.int_est, S.estB + EST_TBL, pos_add(pt0, d), L, I);
       } else {              // lq: the same from t80 with lq_int_length      dsp_icpc.jl:144
         const float d = (e == 4) ? 0.f : (e == 5 ? P.lq_d1 : P.lq_d2);
-        v = estimate(P.int_est, pos_add(ptx[2], d), L, I);
+        v = estimate(P.int_est, S.estB + EST_TBL, pos_add(ptx[2], d), L, I);
       }
       if (lane == 0) eslot[e] = v;
     }
@@ -1113,7 +1131,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
 #pragma unroll
           for (int e = 0; e < 4; ++e) go[e] = (i0 + e < ng) ? go[e] : -INFINITY;
         }
-        gmax = fmaxf(gmax, fmaxf(fmaxf(go[0], go[1]), fmaxf(go[2], go[3])));
+        gmax = vmax3(vmax3(gmax, go[0], go[1]), go[2], go[3]);
         if (wfirst <= P.cur_until[0] && wlast >= P.cur_from[0]) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -1337,11 +1355,20 @@ pz_trap_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, flo
   const TrapDev tr = P.fixed[0];
   const int nout = L - tr.flen + 1;
   float mx = -INFINITY;
+  // unscaled trapezoid exactly as icpc_kernel's sweep B evaluates it; rows wholly inside the
+  // output range skip the per-lane test
+  const float* tb = &B[tid];
+  const float *fa = tb + tr.n1, *fb = tb + tr.n1 + tr.g, *fc = tb + tr.flen;
 #pragma unroll
   for (int m = 0; m < SP; ++m) {
-    const int k = tid + NT * m;
-    if (k < nout) mx = fmaxf(mx, trap_at(B, k, tr));
+    if (NT * (m + 1) <= nout) {
+      mx = vmax(mx, fmaf(fc[NT * m] - fb[NT * m], tr.rr, -(fa[NT * m] - tb[NT * m])));
+    } else if (NT * m < nout) {
+      const float o = fmaf(fc[NT * m] - fb[NT * m], tr.rr, -(fa[NT * m] - tb[NT * m]));
+      mx = vmax(mx, (tid + NT * m < nout) ? o : -INFINITY);
+    }
   }
+  mx *= tr.inv1;
   mx = wave_max_all(mx);
   if (lane == 0) fred[wave] = mx;
   __syncthreads();

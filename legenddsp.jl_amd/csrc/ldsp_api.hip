@@ -368,10 +368,10 @@ int ldsp_icpc_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_param
   }
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->icpc_host.L == 16 * c->icpc_host.NT, c->d_icpc, c->d_aux, od, c->icpc_host.cusp_mode == 0,
-                      c->icpc_host.cz_shared != 0, c->dbg_stop != 0,
+                      c->icpc_host.cz_shared != 0, c->dbg_stop > 0 && c->dbg_stop < 10,
                       ((std::max(c->icpc_host.cusp.Lf, c->icpc_host.zac.Lf) + 2 + 7) & ~3), c->stream,
                       c->timing ? c->evm : nullptr));
-  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = c->dbg_stop ? 1 : 2; }
+  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = (c->dbg_stop > 0 && c->dbg_stop < 10) ? 1 : 2; }
   return LDSP_OK;
 }
 

@@ -35,6 +35,13 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// max / min without the canonicalising `v_max_f32 x, x, x` hipcc puts in front of fmaxf/fminf when it
+// cannot prove an operand is not a signalling NaN (a NaN operand is ignored, as with fmaxf)
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 // ---- fused DPP steps -------------------------------------------------------------
 // One VALU instruction per scan step: `v = op(dpp(v), v)` in place.  Without bound_ctrl a
 // lane whose DPP source is out of range (or whose row is masked off) is simply not

@@ -13,3 +13,11 @@ for stop in (1, 2, 3, 4, 5, 6, 0):
     ldsp.icpc_run(wf, p, ctx); torch.cuda.synchronize()
     ms = min((ldsp.icpc_run(wf, p, ctx), ctx.last_kernel_ms())[1] for _ in range(3))
     print(f"stop after phase {stop}: {ms:.3f} ms (+{ms-prev:.3f})  {ms/n*1e3:.3f} us/wf"); prev = ms
+
+# stops inside icpc_cz_kernel (kernel 1 runs in full): stage 1 = the CZ kernel alone
+prev = 0
+for stop, name in ((11, "load + y rebuild"), (12, "A0 Dp + A1 flat top/u"), (13, "d + B causal"), (14, "C anti-causal"), (15, "A2 parabola"), (0, "finish")):
+    ctx.set_option("dbg_stop", stop)
+    ldsp.icpc_run(wf, p, ctx); torch.cuda.synchronize()
+    ms = min((ldsp.icpc_run(wf, p, ctx), ctx.last_stage_ms(1))[1] for _ in range(3))
+    print(f"cz stop {stop:2d} ({name}): {ms:.3f} ms (+{ms-prev:.3f})"); prev = ms
