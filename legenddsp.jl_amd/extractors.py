@@ -169,6 +169,9 @@ class IntersectMaximum:
     def __call__(self, w: ArrayOfRDWaveforms, threshold):
         ctx, x = _prep(w)
         n, dev = x.shape[0], x.device
+        if x.shape[1] == 0:   # empty waveforms: empty vectors, multiplicity 0 (reference test/test_intersect_maximum.jl:81-90)
+            empty = lambda: VectorOfVectors(torch.zeros(n + 1, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.float32, device=dev))
+            return dict(x=empty(), x_high=empty(), x_tot=empty(), max=empty(), multiplicity=torch.zeros(n, dtype=torch.int32, device=dev))
         thr = _per_trace(threshold, n, dev)
         min_n, max_n = max(1, nsamples(self.mintot, w.dt)), max(1, nsamples(self.maxtot, w.dt))
         cap = _abi.LDSP_MAX_TRIG
