@@ -119,7 +119,10 @@ def main():
         kernel_ms.append(ctx.last_kernel_ms())
         if args.workload == "icpc":
             stage_ms[0].append(ctx.last_stage_ms(0))
-            stage_ms[1].append(ctx.last_stage_ms(1))
+            try:   # two launches only when the CUSP/ZAC stage could not be fused
+                stage_ms[1].append(ctx.last_stage_ms(1))
+            except ldsp.LdspError:
+                pass
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -129,15 +132,16 @@ def main():
         total = n * world * args.steps
         wps = total / elapsed
         kms = sum(kernel_ms) / len(kernel_ms)
-        # one trace read + one output row written.  dsp_icpc runs as two kernels
-        # (DESIGN.md §kernels); the roofline entry is for the dominant one, icpc_kernel, which
-        # reads the trace (4L), writes 42 columns and a 16-byte hand-over record; icpc_cz_kernel
-        # reads the trace again plus that record and writes the 6 CUSP/ZAC columns.
+        # one trace read (4L) + one output row written (4 bytes x 48 columns).  dsp_icpc runs as ONE
+        # launch of icpc_kernel (CUSP/ZAC fused in), so the dominant kernel's algorithmic bytes are
+        # the path's.  If the fused form was not applicable (two launches), icpc_kernel writes 42 columns + a
+        # 16-byte hand-over record and icpc_cz_kernel reads the trace again and writes the other 6.
         chain_bytes = 4 * L + (4 * ncol if args.workload == "icpc" else 8)
+        fused = args.workload == "icpc" and not stage_ms[1]
         if args.workload == "icpc":
             k1 = sum(stage_ms[0]) / len(stage_ms[0])
-            k2 = sum(stage_ms[1]) / len(stage_ms[1])
-            bytes_per_trace = 4 * L + 4 * 42 + 16
+            k2 = sum(stage_ms[1]) / len(stage_ms[1]) if stage_ms[1] else 0.0
+            bytes_per_trace = chain_bytes if fused else 4 * L + 4 * 42 + 16
             dom_ms = k1
         else:
             bytes_per_trace, dom_ms = chain_bytes, kms
@@ -167,9 +171,11 @@ def main():
             res["roofline"]["traffic"] = traffic["bytes"]
             res["roofline"]["traffic_source"] = traffic["source"]
         if args.workload == "icpc":
-            res["roofline"]["chain"] = {  # both kernels together against the path's algorithmic bytes
-                "kernels_ms": {"icpc_kernel": k1, "icpc_cz_kernel": k2}, "algorithmic_bytes_per_trace": chain_bytes,
-                "achieved": n * chain_bytes / (kms * 1e-3) / 1e9, "frac": n * chain_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            res["roofline"]["launches"] = "1 (icpc_kernel, CUSP/ZAC fused)" if fused else "2 (icpc_kernel + icpc_cz_kernel)"
+            if not fused:
+                res["roofline"]["chain"] = {  # both kernels together against the path's algorithmic bytes
+                    "kernels_ms": {"icpc_kernel": k1, "icpc_cz_kernel": k2}, "algorithmic_bytes_per_trace": chain_bytes,
+                    "achieved": n * chain_bytes / (kms * 1e-3) / 1e9, "frac": n * chain_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and args.cpu_sample > 0 and args.workload == "icpc":
             from oracle import oracle as orc  # checker / CPU baseline only
             orc.build()

@@ -61,7 +61,12 @@ int ldsp_ctx_use_own_stream(ldsp_ctx* ctx);
 int ldsp_ctx_synchronize(ldsp_ctx* ctx);
 const char* ldsp_last_error_string(void);
 /* Options: "cusp_direct" = 1 evaluates CUSP/ZAC as direct-form FIR (slow
- * comparator for the closed-form recursions), 0 (default) = recursions. */
+ * comparator for the closed-form recursions), 0 (default) = recursions.
+ * "two_kernel" = 1 runs the CUSP/ZAC stage as a second launch (icpc_cz_kernel)
+ * instead of fused into icpc_kernel (the default whenever CUSP and ZAC share
+ * their geometry and the LDS budget allows two traces per CU).
+ * "dbg_stop" = k stops the kernels after phase k (profiling aid; outputs are
+ * then incomplete). */
 int ldsp_ctx_set_option(ldsp_ctx* ctx, const char* key, int64_t value);
 /* sizeof() of the ABI structs as compiled: 0 icpc_params, 1 icpc_out,
  * 2 sipm_params, 3 sipm_out, 4 trig_out (binding self-check). */
@@ -71,8 +76,9 @@ int64_t ldsp_abi_sizeof(int which);
  * been enabled; synchronises on the closing event). */
 int ldsp_ctx_enable_timing(ldsp_ctx* ctx, int on);
 int ldsp_ctx_last_kernel_ms(ldsp_ctx* ctx, float* ms);
-/* Per-kernel split of the last ldsp_icpc_run: stage 0 = icpc_kernel (phases up to the
- * Intersect family), stage 1 = icpc_cz_kernel (CUSP/ZAC).  Other calls have one stage. */
+/* Per-kernel split of the last ldsp_icpc_run when it ran as two launches: stage 0 =
+ * icpc_kernel, stage 1 = icpc_cz_kernel (CUSP/ZAC).  A fused run and all other calls have
+ * one stage (asking for stage 1 is an LDSP_ERR_INVALID_ARG). */
 int ldsp_ctx_last_stage_ms(ldsp_ctx* ctx, int stage, float* ms);
 
 /* ---- limits of the built kernels --------------------------------------- */

@@ -65,29 +65,32 @@ enum { IS_LOW, IS_HIGH, IS_TAILBAD, IS_CNT0 };
 constexpr int EST_TBL = LDSP_MAX_EST_PTS * (LDSP_MAX_EST_DEG + 1);
 constexpr int NSUM = 16;  // deterministic f64 sum sites x NW wave partials
 
+// LDS layout of one trace.  Between the two sample arrays lies a gap of `gap` floats: kernel 1
+// keeps its threshold bit-masks there; the CUSP/ZAC stage zero-fills it as the Dp[i < 0] = 0
+// margin in front of B1 (the ZAC parabola taps reach back Lf+2 samples).
 template <int NT, int R, bool MASKS = true>
 struct Smem {
   static constexpr int NW = NT / 64, SP = 4 * R, Lp = NT * SP, NWORDS = Lp / 32;
+  static constexpr int MASK_FLOATS = MASKS ? NMASK * NWORDS : 0;
   float* B0;      // [Lp]      y, later scratch
+  uint32_t* bm;   // [NMASK][NWORDS]   (inside the gap)
   float* B1;      // [Lp+64]   T = exclusive prefix sum of y, later scratch
-  uint32_t* bm;   // [NMASK][NWORDS]
   double* part;   // [2][R*NW] scan partials (alternating buffers)
   double* wsum;   // [NSUM][NW] per-wave partial sums, combined in fixed order
   Slots* sl;
-  float* ylast;   // [R*NW]    y at the last sample of each wave-row
+  float* ylast;   // [R*NW]    (unused)
   float* outv;    // [C_NCOLS]  output row, filled as results become available
   float* misc;    // [16]       small broadcasts
   float* estB;    // [2][EST_TBL] LSQ basis tables of sig_est and int_est
-  static constexpr size_t bytes() {
-    return (size_t)(Lp + Lp + 64) * 4 + (MASKS ? (size_t)NMASK * NWORDS * 4 : 0) + 2 * R * NW * 8 + NSUM * NW * 8 + sizeof(Slots) +
+  static constexpr size_t bytes(int gap) {
+    return (size_t)(Lp + Lp + 64 + gap) * 4 + 2 * R * NW * 8 + NSUM * NW * 8 + sizeof(Slots) +
            R * NW * 4 + C_NCOLS * 4 + 16 * 4 + 2 * EST_TBL * 4 + 64;
   }
-  // pad: floats of zero-filled space in front of B1 (reads at small negative indices)
-  __device__ explicit Smem(unsigned char* raw, int pad = 0) {
+  __device__ explicit Smem(unsigned char* raw, int gap) {
     B0 = reinterpret_cast<float*>(raw);
-    B1 = B0 + Lp + pad;
-    bm = reinterpret_cast<uint32_t*>(B1 + Lp + 64);
-    part = reinterpret_cast<double*>(bm + (MASKS ? NMASK * NWORDS : 0));
+    bm = reinterpret_cast<uint32_t*>(B0 + Lp);
+    B1 = B0 + Lp + gap;
+    part = reinterpret_cast<double*>(B1 + Lp + 64);
     wsum = part + 2 * R * NW;
     sl = reinterpret_cast<Slots*>(wsum + NSUM * NW);
     ylast = reinterpret_cast<float*>(sl + 1);
@@ -252,83 +255,34 @@ __device__ __forceinline__ void load_trace_s4(const float* __restrict__ w, int L
 }  // namespace
 
 // ---------------------------------------------------------------------------
-// Kernel 2 of dsp_icpc: CUSP and ZAC (reference src/dsp_icpc.jl:167-178).
-// A separate launch so that its register allocation and instruction footprint are
-// independent of kernel 1.  It re-reads the trace (served by the Infinity Cache when
-// the host chunks the batch), takes blmean and the t50 position from kernel 1's
-// side buffer, rebuilds y = x - blmean + c*cumsum and evaluates both filters.
 // zero-filled space in front of the Dp array: the ZAC parabola taps reach back Lf+2 samples
 __host__ __device__ inline int cz_pad(const IcpcDev& P) { return ((P.cusp.Lf > P.zac.Lf ? P.cusp.Lf : P.zac.Lf) + 2 + 7) & ~3; }
 
-// WANT_C / WANT_Z: which filters this launch evaluates.  Both = they share sigma / flat /
-// length / tau (one set of recursions); otherwise the host launches the kernel once per filter.
-template <int NT, int R, bool FULL, bool DIRECT, bool WANT_C, bool WANT_Z>
-__global__ void __launch_bounds__(NT, 4)
-icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, const float* __restrict__ aux, IcpcOutDev out) {
-  using SM = Smem<NT, R, false>;
+// ---------------------------------------------------------------------------
+// CUSP and ZAC (reference src/dsp_icpc.jl:167-178) on the register-resident, pole-zero corrected
+// trace y (S4 view; B0 holds the same y).  Called at the end of icpc_kernel (fused, the normal
+// path) or from icpc_cz_kernel (second launch: direct-form comparator, filters with different
+// geometry, or a gap too large for two workgroups per CU).  Requires: the gap in front of B1
+// zero-filled or about to be (a barrier follows inside), B1[Lp..Lp+63] = 0, slots fmx[0..1] = 0
+// and imin[0..1] = INT_MAX.  Fills the six CUSP/ZAC entries of S.outv.
+// WANT_C / WANT_Z: which filters this pass evaluates.  Both = they share sigma / flat /
+// length / tau (one set of recursions).
+template <int NT, int R, bool FULL, bool DIRECT, bool WANT_C, bool WANT_Z, typename SM>
+__device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4], Pos ptx1, int& scan_buf) {
   constexpr int NW = SM::NW, SP = SM::SP, Lp = SM::Lp;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const IcpcDev& P = *Pp;
-  const int L = FULL ? Lp : P.L, tid = threadIdx.x;   // FULL: trace length == the tile, every bounds test folds
+  const int L = FULL ? Lp : P.L, tid = threadIdx.x;
   const int lane = lane_id(), wave = wave_id();
-  const int pad = cz_pad(P);
-  SM S(smem_raw, pad);
-  for (int i = tid; i < pad; i += NT) S.B1[i - pad] = 0.f;  // Dp[i < 0] = 0
-  const float* w = wf + (size_t)blockIdx.x * (size_t)L;
-  int scan_buf = 0;
   auto part_buf = [&]() { double* p = S.part + (scan_buf & 1) * R * NW; ++scan_buf; return p; };
   auto put = [&](int c, float v) { if (tid == 0) S.outv[c] = v; };
-  const float blmean = aux[4 * (size_t)blockIdx.x + 0];
   Pos ptx[2];
-  ptx[1].ip = __float_as_int(aux[4 * (size_t)blockIdx.x + 1]);
-  ptx[1].fp = aux[4 * (size_t)blockIdx.x + 2];
-
-  float y[R][4];
-  load_trace_s4<NT, R, FULL>(w, L, tid, y);
-  for (int i = tid; i < EST_TBL; i += NT) S.estB[i] = P.sig_est.B[i];
-  if (tid < (int)(sizeof(Slots) / 4)) {  // fmx[0..1] (maxima: identity 0) and imin[0..1] (first index: identity INT_MAX) are used here
-    const int o = tid * 4;
-    reinterpret_cast<uint32_t*>(S.sl)[tid] = (o >= (int)offsetof(Slots, imin) && o < (int)offsetof(Slots, imax)) ? 0x7fffffffu : 0u;
-  }
-  if (tid < 64) S.B1[Lp + tid] = 0.f;
-  // y = (x - blmean) + c*cumsum(x - blmean), exactly as kernel 1 computes it
-  {
-    float tot[R];
-    double s_off[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i0 = 4 * (tid + NT * r);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) y[r][e] = (i0 + e < L) ? y[r][e] - blmean : 0.f;
-      tot[r] = (y[r][0] + y[r][1]) + (y[r][2] + y[r][3]);
-    }
-    s4_exscan_sum<NT, R>(tot, s_off, part_buf(), nullptr);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i0 = 4 * (tid + NT * r);
-      const float coff = (float)(P.pz_c64 * s_off[r]);
-      float run = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        run += y[r][e];
-        y[r][e] = (i0 + e < L) ? (y[r][e] + coff) + P.pz_c * run : 0.f;
-      }
-      *reinterpret_cast<float4*>(&S.B0[i0]) = make_float4(y[r][0], y[r][1], y[r][2], y[r][3]);
-      if (lane == 63) S.ylast[r * NW + wave] = y[r][3];
-    }
-  }
-  __syncthreads();
+  ptx[1] = ptx1;
   if (P.dbg_stop == 11) return;  // profiling aid (tools/gpu_phase_time.py): stops 11..15 inside this kernel
-  // y just before each of the thread's chunks (for d[i] = y[i] - a*y[i-1])
+  // y just before each of the thread's chunks (for d[i] = y[i] - a*y[i-1]); B0 = y here
   float yprev[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    float pv = dpp_f<0x138>(0.f, y[r][3]);  // wave_shr:1
-    if (lane == 0) {
-      const int idx = r * NW + wave;
-      pv = (idx > 0) ? S.ylast[idx - 1] : 0.f;
-    }
-    yprev[r] = pv;
+    const int i0 = 4 * (tid + NT * r);
+    yprev[r] = (i0 > 0) ? S.B0[i0 - 1] : 0.f;
   }
   // extremestats + SignalEstimator on filter outputs held in the LS view
   // (acc[m] = out[tid + NT*m]); f = 0 CUSP, 1 ZAC.          dsp_icpc.jl:170-171,177-178
@@ -642,6 +596,66 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
     if (WANT_C) finish_collect(0, P.cusp.Lf);
     if (WANT_Z) finish_collect(1, P.zac.Lf);
   }
+}
+
+// Second-launch form of the CUSP/ZAC stage: re-reads the trace, takes blmean and the t50 position
+// from kernel 1's side buffer and rebuilds y = x - blmean + c*cumsum exactly as kernel 1 does.
+template <int NT, int R, bool FULL, bool DIRECT, bool WANT_C, bool WANT_Z>
+__global__ void __launch_bounds__(NT, 4)
+icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, const float* __restrict__ aux, IcpcOutDev out) {
+  using SM = Smem<NT, R, false>;
+  constexpr int NW = SM::NW, SP = SM::SP, Lp = SM::Lp;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const IcpcDev& P = *Pp;
+  const int L = FULL ? Lp : P.L, tid = threadIdx.x;   // FULL: trace length == the tile, every bounds test folds
+  const int lane = lane_id(), wave = wave_id();
+  const int pad = cz_pad(P);
+  SM S(smem_raw, pad);
+  for (int i = tid; i < pad; i += NT) S.B1[i - pad] = 0.f;  // Dp[i < 0] = 0
+  const float* w = wf + (size_t)blockIdx.x * (size_t)L;
+  int scan_buf = 0;
+  auto part_buf = [&]() { double* p = S.part + (scan_buf & 1) * R * NW; ++scan_buf; return p; };
+  auto put = [&](int c, float v) { if (tid == 0) S.outv[c] = v; };
+  const float blmean = aux[4 * (size_t)blockIdx.x + 0];
+  Pos ptx[2];
+  ptx[1].ip = __float_as_int(aux[4 * (size_t)blockIdx.x + 1]);
+  ptx[1].fp = aux[4 * (size_t)blockIdx.x + 2];
+
+  float y[R][4];
+  load_trace_s4<NT, R, FULL>(w, L, tid, y);
+  for (int i = tid; i < EST_TBL; i += NT) S.estB[i] = P.sig_est.B[i];
+  if (tid < (int)(sizeof(Slots) / 4)) {  // fmx[0..1] (maxima: identity 0) and imin[0..1] (first index: identity INT_MAX) are used here
+    const int o = tid * 4;
+    reinterpret_cast<uint32_t*>(S.sl)[tid] = (o >= (int)offsetof(Slots, imin) && o < (int)offsetof(Slots, imax)) ? 0x7fffffffu : 0u;
+  }
+  if (tid < 64) S.B1[Lp + tid] = 0.f;
+  // y = (x - blmean) + c*cumsum(x - blmean), exactly as kernel 1 computes it
+  {
+    float tot[R];
+    double s_off[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i0 = 4 * (tid + NT * r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[r][e] = (i0 + e < L) ? y[r][e] - blmean : 0.f;
+      tot[r] = (y[r][0] + y[r][1]) + (y[r][2] + y[r][3]);
+    }
+    s4_exscan_sum<NT, R>(tot, s_off, part_buf(), nullptr);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i0 = 4 * (tid + NT * r);
+      const float coff = (float)(P.pz_c64 * s_off[r]);
+      float run = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        run += y[r][e];
+        y[r][e] = (i0 + e < L) ? (y[r][e] + coff) + P.pz_c * run : 0.f;
+      }
+      *reinterpret_cast<float4*>(&S.B0[i0]) = make_float4(y[r][0], y[r][1], y[r][2], y[r][3]);
+    }
+  }
+  __syncthreads();
+  cz_body<NT, R, FULL, DIRECT, WANT_C, WANT_Z>(S, P, y, ptx[1], scan_buf);
   __syncthreads();
   if (tid < 6) {
     const int cols[6] = {C_e_cusp, C_e_zac, C_e_cusp_max, C_e_zac_max, C_t_cusp_max, C_t_zac_max};
@@ -652,7 +666,10 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
   }
 }
 
-template <int NT, int R, bool FULL>
+// FUSE: the CUSP/ZAC stage runs at the end of this kernel on the same registers (one launch, one
+// read of the trace, all 48 columns in one row store); otherwise blmean and the t50 position go
+// to `aux` for icpc_cz_kernel.
+template <int NT, int R, bool FULL, bool FUSE>
 __global__ void __launch_bounds__(NT, 4)  // 4 waves/SIMD: <= 128 VGPRs, two 512-thread traces per CU
 icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float* __restrict__ aux, IcpcOutDev out) {
   using SM = Smem<NT, R>;
@@ -661,7 +678,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   const IcpcDev& P = *Pp;
   const int L = FULL ? Lp : P.L, tid = threadIdx.x;   // FULL: trace length == the tile, every bounds test folds
   const int lane = lane_id(), wave = wave_id();
-  SM S(smem_raw);
+  SM S(smem_raw, FUSE ? max(SM::MASK_FLOATS, cz_pad(P)) : SM::MASK_FLOATS);
   const float* w = wf + (size_t)blockIdx.x * (size_t)L;
   int scan_buf = 0;
   auto part_buf = [&]() { double* p = S.part + (scan_buf & 1) * R * NW; ++scan_buf; return p; };
@@ -1268,11 +1285,21 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   }
   if (P.dbg_stop == 6) return;
 
-  // CUSP / ZAC run in icpc_cz_kernel; hand over blmean and the t50 position
-  if (tid == 0) {
-    aux[4 * (size_t)blockIdx.x + 0] = blmean;
-    aux[4 * (size_t)blockIdx.x + 1] = __int_as_float(ptx[1].ip);
-    aux[4 * (size_t)blockIdx.x + 2] = ptx[1].fp;
+  if constexpr (FUSE) {
+    // ------------------------------------------- phase 5: CUSP / ZAC (dsp_icpc.jl:167-178)
+    __syncthreads();  // every phase-4 read of the mask words, the SG output and the slots is done
+    const int pad = cz_pad(P);
+    for (int i = tid; i < pad; i += NT) S.B1[i - pad] = 0.f;  // the gap (dead mask words) becomes Dp[i < 0] = 0
+    if (tid < 64) S.B1[Lp + tid] = 0.f;
+    if (tid < 2) { S.sl->fmx[tid] = 0u; S.sl->imin[tid] = 0x7fffffff; }
+    cz_body<NT, R, FULL, false, true, true>(S, P, y, ptx[1], scan_buf);  // barriers inside order the above
+  } else {
+    // CUSP / ZAC run in icpc_cz_kernel; hand over blmean and the t50 position
+    if (tid == 0) {
+      aux[4 * (size_t)blockIdx.x + 0] = blmean;
+      aux[4 * (size_t)blockIdx.x + 1] = __int_as_float(ptx[1].ip);
+      aux[4 * (size_t)blockIdx.x + 2] = ptx[1].fp;
+    }
   }
   // ---------------------------------------------------------------- outputs
   __syncthreads();
@@ -1280,7 +1307,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     const bool cz_col = tid == C_e_cusp || tid == C_e_zac || tid == C_e_cusp_max || tid == C_e_zac_max ||
                         tid == C_t_cusp_max || tid == C_t_zac_max;
     float* dst = reinterpret_cast<float*>(out.col[tid]);
-    if (dst && !cz_col) dst[(size_t)blockIdx.x * (size_t)out.stride] = S.outv[tid];
+    if (dst && (FUSE || !cz_col)) dst[(size_t)blockIdx.x * (size_t)out.stride] = S.outv[tid];
   }
 }
 
@@ -1379,18 +1406,35 @@ pz_trap_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, flo
   }
 }
 
+// Largest dynamic LDS size that still lets two workgroups share a CU (160 KiB, 1280-byte granules)
+constexpr size_t LDS_TWO_PER_CU = 80640;
+
 template <int NT, int R, bool FULL>
 static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
-                                bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid) {
-  const size_t smem = Smem<NT, R>::bytes();
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_kernel<NT, R, FULL>),
+                                bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st,
+                                hipEvent_t mid, int* stages) {
+  using SM = Smem<NT, R>;
+  // fused single launch: the normal path (both filters share their geometry, closed form, the gap fits)
+  const size_t smem_fused = SM::bytes(std::max(SM::MASK_FLOATS, cz_pad_floats));
+  if (fuse_ok && !direct && cz_shared && smem_fused <= LDS_TWO_PER_CU) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_kernel<NT, R, FULL, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_fused);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((icpc_kernel<NT, R, FULL, true>), dim3((unsigned)n), dim3(NT), smem_fused, st, wf, dP, aux, out);
+    *stages = 1;
+    return hipGetLastError();
+  }
+  const size_t smem = SM::bytes(SM::MASK_FLOATS);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_kernel<NT, R, FULL, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((icpc_kernel<NT, R, FULL>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, aux, out);
+  hipLaunchKernelGGL((icpc_kernel<NT, R, FULL, false>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, aux, out);
   e = hipGetLastError();
+  *stages = 1;
   if (e == hipSuccess && mid) e = hipEventRecord(mid, st);  // stage boundary for per-kernel timing
   if (e != hipSuccess || stop_after_main) return e;
-  const size_t smem_cz = Smem<NT, R, false>::bytes() + (size_t)cz_pad_floats * 4;
+  *stages = 2;
+  const size_t smem_cz = Smem<NT, R, false>::bytes(cz_pad_floats);
   auto launch_cz = [&](auto kern) -> hipError_t {
     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_cz);
     if (e2 != hipSuccess) return e2;
@@ -1403,13 +1447,15 @@ static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, f
   if (e != hipSuccess) return e;
   return launch_cz(&icpc_cz_kernel<NT, R, FULL, false, false, true>);
 }
-// `full`: the trace length equals the tile (L == 16*NT), the specialisation without bounds tests
+// `full`: the trace length equals the tile (L == 16*NT), the specialisation without bounds tests.
+// *stages: number of timed stages of this call (1 = fused launch, 2 = icpc_kernel + icpc_cz_kernel)
 hipError_t launch_icpc(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
-                       bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid) {
-#define LDSP_CASE(N)                                                                                                        \
-  case N:                                                                                                                   \
-    return full ? launch_icpc_t<N, 4, true>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid) \
-                : launch_icpc_t<N, 4, false>(wf, n, dP, aux, out, direct, cz_shared, stop_after_main, cz_pad_floats, st, mid);
+                       bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid,
+                       int* stages) {
+#define LDSP_CASE(N)                                                                                                                 \
+  case N:                                                                                                                            \
+    return full ? launch_icpc_t<N, 4, true>(wf, n, dP, aux, out, direct, cz_shared, fuse_ok, stop_after_main, cz_pad_floats, st, mid, stages) \
+                : launch_icpc_t<N, 4, false>(wf, n, dP, aux, out, direct, cz_shared, fuse_ok, stop_after_main, cz_pad_floats, st, mid, stages);
   switch (NT) {
     LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
     default: return hipErrorInvalidValue;

@@ -17,7 +17,8 @@
 
 namespace ldsp {
 hipError_t launch_icpc(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
-                       bool direct, bool cz_shared, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid);
+                       bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid,
+                       int* stages);
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 size_t icpc_smem_bytes(int NT);
 }  // namespace ldsp
@@ -117,6 +118,7 @@ int ldsp_ctx_synchronize(ldsp_ctx* c) {
 int ldsp_ctx_set_option(ldsp_ctx* c, const char* key, int64_t value) {
   if (!c || !key) return fail(LDSP_ERR_INVALID_ARG, "ctx/key is NULL");
   if (!strcmp(key, "cusp_direct")) { c->cusp_direct = value != 0; return LDSP_OK; }
+  if (!strcmp(key, "two_kernel")) { c->two_kernel = value != 0; return LDSP_OK; }
   if (!strcmp(key, "dbg_stop")) { c->dbg_stop = (int)value; c->icpc_valid = false; return LDSP_OK; }
   return fail(LDSP_ERR_INVALID_ARG, "unknown option '%s'", key);
 }
@@ -367,11 +369,12 @@ int ldsp_icpc_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_param
     c->aux_cap = n;
   }
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  int stages = 1;
   HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->icpc_host.L == 16 * c->icpc_host.NT, c->d_icpc, c->d_aux, od, c->icpc_host.cusp_mode == 0,
-                      c->icpc_host.cz_shared != 0, c->dbg_stop > 0 && c->dbg_stop < 10,
+                      c->icpc_host.cz_shared != 0, !c->two_kernel, c->dbg_stop > 0 && c->dbg_stop < 10,
                       ((std::max(c->icpc_host.cusp.Lf, c->icpc_host.zac.Lf) + 2 + 7) & ~3), c->stream,
-                      c->timing ? c->evm : nullptr));
-  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = (c->dbg_stop > 0 && c->dbg_stop < 10) ? 1 : 2; }
+                      c->timing ? c->evm : nullptr, &stages));
+  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = stages; }
   return LDSP_OK;
 }
 

@@ -30,6 +30,7 @@ struct ldsp_ctx {
   int64_t aux_cap = 0;
   float* d_coef = nullptr;  // [LDSP_MAX_FIR_TAPS] staging for functor coefficients / small tables
   int cusp_direct = 0;
+  int two_kernel = 0;   // option "two_kernel": never fuse the CUSP/ZAC stage into icpc_kernel
   int dbg_stop = 0;
   // timing
   int timing = 0;

@@ -8,16 +8,16 @@ p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, L, 0.0
 wf = ldsp.synth.hpge_batch(n, L, device="cuda")
 ctx = ldsp.default_context(); ctx.enable_timing(True)
 prev = 0
-for stop in (1, 2, 3, 4, 5, 6, 0):
+for stop in (1, 2, 3, 4, 5, 6):
     ctx.set_option("dbg_stop", stop)
     ldsp.icpc_run(wf, p, ctx); torch.cuda.synchronize()
     ms = min((ldsp.icpc_run(wf, p, ctx), ctx.last_kernel_ms())[1] for _ in range(3))
     print(f"stop after phase {stop}: {ms:.3f} ms (+{ms-prev:.3f})  {ms/n*1e3:.3f} us/wf"); prev = ms
 
-# stops inside icpc_cz_kernel (kernel 1 runs in full): stage 1 = the CZ kernel alone
-prev = 0
-for stop, name in ((11, "load + y rebuild"), (12, "A0 Dp + A1 flat top/u"), (13, "d + B causal"), (14, "C anti-causal"), (15, "A2 parabola"), (0, "finish")):
+# stops inside the CUSP/ZAC stage (fused: same launch; kernel 1's phases run in full before it)
+base = prev
+for stop, name in ((11, "y ready"), (12, "A0 Dp + A1 flat top/u"), (13, "d + B causal"), (14, "C anti-causal"), (15, "A2 parabola"), (0, "finish")):
     ctx.set_option("dbg_stop", stop)
     ldsp.icpc_run(wf, p, ctx); torch.cuda.synchronize()
-    ms = min((ldsp.icpc_run(wf, p, ctx), ctx.last_stage_ms(1))[1] for _ in range(3))
+    ms = min((ldsp.icpc_run(wf, p, ctx), ctx.last_kernel_ms())[1] for _ in range(3))
     print(f"cz stop {stop:2d} ({name}): {ms:.3f} ms (+{ms-prev:.3f})"); prev = ms
