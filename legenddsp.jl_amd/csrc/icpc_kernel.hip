@@ -267,7 +267,7 @@ __host__ __device__ inline int cz_pad(const IcpcDev& P) { return ((P.cusp.Lf > P
 // and imin[0..1] = INT_MAX.  Fills the six CUSP/ZAC entries of S.outv.
 // WANT_C / WANT_Z: which filters this pass evaluates.  Both = they share sigma / flat /
 // length / tau (one set of recursions).
-template <int NT, int R, bool FULL, bool DIRECT, bool WANT_C, bool WANT_Z, typename SM>
+template <int NT, int R, bool FULL, bool DIRECT, bool WANT_C, bool WANT_Z, bool T_READY, typename SM>
 __device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4], Pos ptx1, int& scan_buf) {
   constexpr int NW = SM::NW, SP = SM::SP, Lp = SM::Lp;
   const int L = FULL ? Lp : P.L, tid = threadIdx.x;
@@ -383,9 +383,19 @@ __device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4
       const CuspZacDev& Z = WANT_C ? P.cusp : P.zac;       // geometry + exponentials of this launch
       const CuspZacDev& ZZ = P.zac;                         // parabola constants
       const int Lf = Z.Lf, nout = L - Lf + 1, lt = Z.lt, f1 = Z.f1, ltp = Z.ltp;
-      // ---- step A0 (S4): Dp[i] = y[i]-y[0]+eps*T[i] -> B1, T re-derived by a scan of the
-      // register-resident y (B1 held the SG output; its reads are behind the last barrier)
-      {
+      // ---- step A0 (S4): Dp[i] = y[i]-y[0]+eps*T[i] -> B1.  T_READY (fused): B1 still holds T, each
+      // thread converts its own quads in place; otherwise T is re-derived by a scan of the
+      // register-resident y.
+      if constexpr (T_READY) {
+        const float y0 = S.B0[0];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float4 t = *reinterpret_cast<const float4*>(&S.B1[4 * (tid + NT * r)]);
+          t.x = fmaf(Z.eps, t.x, y[r][0] - y0); t.y = fmaf(Z.eps, t.y, y[r][1] - y0);
+          t.z = fmaf(Z.eps, t.z, y[r][2] - y0); t.w = fmaf(Z.eps, t.w, y[r][3] - y0);
+          *reinterpret_cast<float4*>(&S.B1[4 * (tid + NT * r)]) = t;
+        }
+      } else {
         if (tid == 0) S.misc[2] = y[0][0];  // y[0] for everyone
         float tot[R];
         double t_off[R];
@@ -655,7 +665,7 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
     }
   }
   __syncthreads();
-  cz_body<NT, R, FULL, DIRECT, WANT_C, WANT_Z>(S, P, y, ptx[1], scan_buf);
+  cz_body<NT, R, FULL, DIRECT, WANT_C, WANT_Z, false>(S, P, y, ptx[1], scan_buf);
   __syncthreads();
   if (tid < 6) {
     const int cols[6] = {C_e_cusp, C_e_zac, C_e_cusp_max, C_e_zac_max, C_t_cusp_max, C_t_zac_max};
@@ -858,251 +868,20 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   }
   auto& y = x;
 
-  // ------------------------------------------------- phase 2: T = prefix sum of y
-  float pv_pz;
-  {
-    float tot[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i0 = 4 * (tid + NT * r);
-      tot[r] = (y[r][0] + y[r][1]) + (y[r][2] + y[r][3]);
-      *reinterpret_cast<float4*>(&S.B0[i0]) = make_float4(y[r][0], y[r][1], y[r][2], y[r][3]);
-    }
-    double t_off[R], tot_all;
-    s4_exscan_sum<NT, R>(tot, t_off, part_buf(), &tot_all);   // barrier inside: B0 = y is visible
-    // signalstats of the pole-zero corrected tail (dsp_icpc.jl:122), pivot = its first sample
-    WinAccF pz = {0, 0, 0};
-    pv_pz = S.B0[P.tail.from];
-    const float ficp = (float)P.tail.ic;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i0 = 4 * (tid + NT * r);
-      winf_accum4(pz, P.tail, i0, (float)i0 - ficp, pv_pz, y[r][0], y[r][1], y[r][2], y[r][3]);
-      double run = t_off[r];
-      float4 t;
-      float* pt = &t.x;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { pt[e] = (float)run; run += (double)y[r][e]; }
-      *reinterpret_cast<float4*>(&S.B1[i0]) = t;
-    }
-    win_publish<NW>(pz, S.wsum, 6);
-    if (tid == 0) S.B1[Lp] = (float)tot_all;  // T[Lp] (= T[L] when L == Lp; y is 0 beyond L)
-    for (int i = tid; i < 7 * NWORDS / 4; i += NT)  // phase-3 mask words: only non-zero ballots are stored
-      reinterpret_cast<uint4*>(S.bm)[i] = make_uint4(0u, 0u, 0u, 0u);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float tailmean, tailsigma, tailslope, tailoffset;
-    win_finish(win_collect<NW>(S.wsum, 6), P.tail, pv_pz, P.t_first, P.dt, &tailmean, &tailsigma, &tailslope, &tailoffset);
-    S.outv[C_tailmean] = tailmean; S.outv[C_tailsigma] = tailsigma; S.outv[C_tailslope] = tailslope; S.outv[C_tailoffset] = tailoffset;
-  }
-  if (P.dbg_stop == 2) return;
-
-  // ------------------------------------------------ phase 3: lane-strided sweep
-  const float thr_tx[5] = {e_max * 0.1f, e_max * 0.5f, e_max * 0.8f, e_max * 0.9f, e_max * 0.99f};
-  {
-    float mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY, mn0 = INFINITY, mn2 = INFINITY;
-    float bo_v = -INFINITY; int bo_i = 0x7fffffff;
-    const int nout_t0 = L - P.t0.flen + 1, nout_t0i = L - P.t0inv.flen + 1;
-    const int nout_f0 = L - P.fixed[0].flen + 1, nout_f1 = L - P.fixed[1].flen + 1,
-              nout_f2 = L - P.fixed[2].flen + 1, nout_opt = L - P.opt.flen + 1;
-    const TrapDev t0 = P.t0, t0i = P.t0inv, f0 = P.fixed[0], f1 = P.fixed[1], f2 = P.fixed[2], fo = P.opt;
-    const bool inv_same = P.t0inv_same != 0;
-    // One base register per shifted read; the row offset NT*m is an immediate.  A trapezoid is
-    // evaluated unscaled, o' = (T[k+flen]-T[k+n1+g])*(inv2/inv1) - (T[k+n1]-T[k]) (two subtractions and
-    // one fma), thresholds are divided by inv1 and maxima multiplied by it after the sweep.
-    // Rows wholly inside an output range skip the per-lane range test (scalar branch on the row).
-    const float* tb = &S.B1[tid];
-    auto traw = [&](const float* a, const float* b, const float* c, float rr, float Tk, int m) {
-      return fmaf(c[NT * m] - b[NT * m], rr, -(a[NT * m] - Tk));
-    };
-    // ---- sweep A: threshold bit-masks of y (5) and of the t0 trapezoid (2)
-    {
-      const float* yb = &S.B0[tid];
-      const float *t0a = tb + t0.n1, *t0b = tb + t0.n1 + t0.g, *t0c = tb + t0.flen;
-      const float *tia = tb + t0i.n1, *tib = tb + t0i.n1 + t0i.g, *tic = tb + t0i.flen;
-      const float rr0 = t0.rr, rri = t0i.rr;
-      const float thr0 = P.t0_thr * t0.navg, thr0i = -P.t0_thr * t0i.navg;
-#pragma unroll
-      for (int m = 0; m < SP; ++m) {
-        const int k = tid + NT * m;
-        float yv = yb[NT * m];
-        if (!FULL && NT * (m + 1) > L) yv = (k < L) ? yv : -INFINITY;
-        unsigned long long bq[7];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) bq[q] = __ballot(yv >= thr_tx[q]);
-        const float Tk = tb[NT * m];
-        float o0 = NAN, o0i = NAN;   // NaN: both comparisons false for rows/lanes outside the output range
-        if (NT * (m + 1) <= nout_t0) o0 = traw(t0a, t0b, t0c, rr0, Tk, m);
-        else if (NT * m < nout_t0) { o0 = traw(t0a, t0b, t0c, rr0, Tk, m); o0 = (k < nout_t0) ? o0 : NAN; }
-        if (inv_same) o0i = o0;
-        else if (NT * (m + 1) <= nout_t0i) o0i = traw(tia, tib, tic, rri, Tk, m);
-        else if (NT * m < nout_t0i) { o0i = traw(tia, tib, tic, rri, Tk, m); o0i = (k < nout_t0i) ? o0i : NAN; }
-        bq[M_T0] = __ballot(o0 >= thr0);
-        bq[M_T0INV] = __ballot(o0i <= thr0i);   // -trap >= thr
-        // the mask words were zeroed in phase 2: all-zero ballots (most rows of the t0 masks, the
-        // baseline rows of the y masks) are not stored.  thr_tx ascends, so bq[0] covers bq[1..4].
-        if (lane == 0) {
-          const int wb = (NT >> 5) * m + 2 * wave;
-          if (bq[0] | (e_max <= 0.f ? ~0ull : 0ull)) {
-#pragma unroll
-            for (int q = 0; q < 5; ++q) *reinterpret_cast<unsigned long long*>(&S.bm[q * NWORDS + wb]) = bq[q];
-          }
-          if (bq[M_T0]) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0 * NWORDS + wb]) = bq[M_T0];
-          if (bq[M_T0INV]) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0INV * NWORDS + wb]) = bq[M_T0INV];
-        }
-      }
-    }
-    // ---- sweep B: extrema of the three fixed trapezoids and the arg-max of the optimised one
-    {
-      const float *f0a = tb + f0.n1, *f0b = tb + f0.n1 + f0.g, *f0c = tb + f0.flen;
-      const float *f1a = tb + f1.n1, *f1b = tb + f1.n1 + f1.g, *f1c = tb + f1.flen;
-      const float *f2a = tb + f2.n1, *f2b = tb + f2.n1 + f2.g, *f2c = tb + f2.flen;
-      const float *foa = tb + fo.n1, *fob = tb + fo.n1 + fo.g, *foc = tb + fo.flen;
-      const float rr0 = f0.rr, rr1 = f1.rr, rr2 = f2.rr, rro = fo.rr;
-#pragma unroll
-      for (int m = 0; m < SP; ++m) {
-        const int k = tid + NT * m;
-        const float Tk = tb[NT * m];
-        if (NT * (m + 1) <= nout_f0) {
-          const float o = traw(f0a, f0b, f0c, rr0, Tk, m);
-          mx0 = vmax(mx0, o); mn0 = vmin(mn0, o);
-        } else if (NT * m < nout_f0) {
-          const float o = traw(f0a, f0b, f0c, rr0, Tk, m);
-          mx0 = vmax(mx0, (k < nout_f0) ? o : -INFINITY); mn0 = vmin(mn0, (k < nout_f0) ? o : INFINITY);
-        }
-        if (NT * (m + 1) <= nout_f1) mx1 = vmax(mx1, traw(f1a, f1b, f1c, rr1, Tk, m));
-        else if (NT * m < nout_f1) { const float o = traw(f1a, f1b, f1c, rr1, Tk, m); mx1 = vmax(mx1, (k < nout_f1) ? o : -INFINITY); }
-        if (NT * (m + 1) <= nout_f2) {
-          const float o = traw(f2a, f2b, f2c, rr2, Tk, m);
-          mx2 = vmax(mx2, o); mn2 = vmin(mn2, o);
-        } else if (NT * m < nout_f2) {
-          const float o = traw(f2a, f2b, f2c, rr2, Tk, m);
-          mx2 = vmax(mx2, (k < nout_f2) ? o : -INFINITY); mn2 = vmin(mn2, (k < nout_f2) ? o : INFINITY);
-        }
-        if (NT * (m + 1) <= nout_opt) {
-          const float o = traw(foa, fob, foc, rro, Tk, m);
-          if (o > bo_v) { bo_v = o; bo_i = k; }
-        } else if (NT * m < nout_opt) {
-          const float o = traw(foa, fob, foc, rro, Tk, m);
-          if (k < nout_opt && o > bo_v) { bo_v = o; bo_i = k; }
-        }
-      }
-      mx0 *= f0.inv1; mn0 *= f0.inv1; mx1 *= f1.inv1; mx2 *= f2.inv1; mn2 *= f2.inv1; bo_v *= fo.inv1;
-    }
-    mx0 = wave_max_all(mx0); mx1 = wave_max_all(mx1); mx2 = wave_max_all(mx2);
-    mn0 = wave_min_all(mn0); mn2 = wave_min_all(mn2);
-    unsigned long long bo = wave_max_u64(pack_vi(bo_v, bo_i));
-    if (lane == 0) {
-      atomicMax(&S.sl->fmx[FX_F0], ford(mx0));
-      atomicMax(&S.sl->fmx[FX_F1], ford(mx1));
-      atomicMax(&S.sl->fmx[FX_F2], ford(mx2));
-      // max(trap(-y)) = -min(trap(y)): negate BEFORE the order map (negating the decoded
-      // slot value was folded into a wrong sign by hipcc 7.2)
-      atomicMax(&S.sl->fmx[FX_F0I], ford(-mn0));
-      atomicMax(&S.sl->fmx[FX_F2I], ford(-mn2));
-      atomicMax(&S.sl->vi[VI_OPT], bo);
-    }
-  }
-  __syncthreads();
-  if (P.dbg_stop == 3) return;
-  // Intersect scans on the bit-masks (thread w <-> word w)
-  for (int j = tid; j < 7 * NWORDS; j += NT) {
-    const int q = j / NWORDS, wd = j - q * NWORDS;
-    const int min_n = (q < 5) ? P.tx_mintot : P.t0_mintot;
-    int c, f;
-    intersect_word(S.bm + q * NWORDS, wd, NWORDS, min_n, &c, &f);
-    if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + q], c); atomicMin(&S.sl->imin[q], f); }
-  }
-  __syncthreads();
-  {
-    float mx_opt_v; int mx_opt_i;
-    unpack_vi(S.sl->vi[VI_OPT], &mx_opt_v, &mx_opt_i);
-    put(C_e_trap_max, mx_opt_v); put(C_t_trap_max, P.t_first + P.dt * (float)(mx_opt_i + P.opt.flen - 1));
-    put(C_e_10410, ford_inv(S.sl->fmx[FX_F0])); put(C_e_535, ford_inv(S.sl->fmx[FX_F1])); put(C_e_313, ford_inv(S.sl->fmx[FX_F2]));
-    // trap(-y) = -trap(y)  (dsp_icpc.jl:199-204)
-    put(C_e_10410_inv, ford_inv(S.sl->fmx[FX_F0I])); put(C_e_313_inv, ford_inv(S.sl->fmx[FX_F2I]));
-  }
-  // crossing positions (sample units, split int + frac); NaN -> 0 us (dsp_routines.jl:24,41).
-  // Seven interpolations, one per lane (lane q < 5: threshold q of y; 5: t0; 6: inverted t0),
-  // evaluated once per wave and handed out by readlane.
-  Pos ptx[3];   // [1] = t50, [2] = t80 (the only ones used further down); pt0
-  Pos pt0;
-  {
-    const int q = min(lane, 6);
-    const bool has = S.sl->isum[IS_CNT0 + q] > 0;
-    const int p = S.sl->imin[q];
-    const float frac = (q == 0) ? 0.1f : (q == 1) ? 0.5f : (q == 2) ? 0.8f : (q == 3) ? 0.9f : 0.99f;
-    const float thr = (q < 5) ? e_max * frac : P.t0_thr;   // same products as thr_tx[]
-    Pos pp; pp.ip = 0; pp.fp = -P.t_first / P.dt;            // sample position of t = 0
-    float us = 0.f;
-    if (has) {
-      float yl, yh; int base;
-      if (q < 5) {
-        yl = S.B0[p - 1]; yh = S.B0[p]; base = p - 1;
-      } else {
-        const bool inv = (q == 6);
-        const TrapDev& t = (inv && !P.t0inv_same) ? P.t0inv : P.t0;
-        yl = trap_at(S.B1, p - 1, t); yh = trap_at(S.B1, p, t);
-        if (inv) { yl = -yl; yh = -yh; }
-        base = p - 1 + (t.flen - 1);  // trailing alignment (A1): back to input index space
-      }
-      pp.ip = base; pp.fp = (thr - yl) / (yh - yl);
-      us = (P.t_first + P.dt * ((float)base + pp.fp)) * P.inv_unit_per_us;
-    } else {
-      pp = pos_norm(pp);
-    }
-    ptx[1].ip = __builtin_amdgcn_readlane(pp.ip, 1); ptx[1].fp = readlane_f(pp.fp, 1);
-    ptx[2].ip = __builtin_amdgcn_readlane(pp.ip, 2); ptx[2].fp = readlane_f(pp.fp, 2);
-    pt0.ip = __builtin_amdgcn_readlane(pp.ip, 5); pt0.fp = readlane_f(pp.fp, 5);
-    if (wave == 0) {
-      if (lane < 7) S.outv[lane == 0 ? C_t10 : lane == 1 ? C_t50 : lane == 2 ? C_t80 : lane == 3 ? C_t90 : lane == 4 ? C_t99 : lane == 5 ? C_t0 : C_t0_inv] = us;
-      const float t90 = readlane_f(us, 3), t0u = readlane_f(us, 5);
-      if (lane == 0) S.outv[C_drift_time] = (t90 - t0u) * P.unit_per_us;
-    }
-  }
-  if (P.dbg_stop == 4) return;
-
-  // ------------------------------------------------ phase 3c: signal estimators
-  // e_trap = SignalEstimator(trap_opt output, t50 + rt + ft/2)     dsp_icpc.jl:163
-  // the seven estimates are spread over the waves (each needs a full wave: lane l = window point l)
-  {
-    float* eslot = S.misc + 4;
-    auto I = [&](int i) { return S.B1[i + 1]; };  // integrator output I[i] = T[i+1]  (dsp_routines.jl:53)
-    for (int e = wave; e < 7; e += NW) {
-      float v;
-      if (e == 0) {
-        Pos p = pos_add(ptx[1], P.trap_pickoff);
-        p.ip -= (P.opt.flen - 1);
-        v = estimate(P.sig_est, S.estB, p, L - P.opt.flen + 1, [&](int i) { return trap_at(S.B1, i, P.opt); });
-      } else if (e <= 3) {  // get_qdrift(wvfs, t0, qdrift_int_length)   dsp_routines.jl:51-64
-        const float d = (e == 1) ? 0.f : (e == 2 ? P.qdrift_d1 : P.qdrift_d2);
-        v = estimate(P.int_est, S.estB + EST_TBL, pos_add(pt0, d), L, I);
-      } else {              // lq: the same from t80 with lq_int_length      dsp_icpc.jl:144
-        const float d = (e == 4) ? 0.f : (e == 5 ? P.lq_d1 : P.lq_d2);
-        v = estimate(P.int_est, S.estB + EST_TBL, pos_add(ptx[2], d), L, I);
-      }
-      if (lane == 0) eslot[e] = v;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      S.outv[C_e_trap] = eslot[0];
-      S.outv[C_qdrift] = (eslot[3] - eslot[2]) - (eslot[2] - eslot[1]);
-      S.outv[C_lq] = (eslot[6] - eslot[5]) - (eslot[5] - eslot[4]);
-    }
-  }
-  if (P.dbg_stop == 5) return;
-
-  // ----------------------------------- phase 4: SG derivatives, current maxima
+  // ----------------------------------- phase 2: SG derivatives, current maxima
+  // (runs before the prefix sum T is built: its full-length output is parked in B1, which T then
+  // takes over and keeps until the CUSP/ZAC stage turns it into Dp in place)
   // LS view: g[k] = sum_i c[i] y[k+i] (valid mode, trailing time axis).  The SG(sg_wl)
-  // output is needed in full (pile-up scan, t50_current) and is parked in B1 (T lives on
-  // in registers); SG(60ns), SG(100ns) and the plain derivative only in the current window.
+  // output is needed in full (pile-up scan, t50_current) and is parked in B1; SG(60ns), SG(100ns) and the plain derivative only in the current window.
   const int ng = L - P.sg_npts[0] + 1;
   auto flt_at = [&](int f, int k) -> float { return flt_eval(S.B0, P.sg_c[f < 3 ? f : 0], P.sg_npts[f < 3 ? f : 0], f, k); };
   auto flt_rare = [&](int f, int k) -> float { return flt_eval_rare(S.B0, P.sg_c[f < 3 ? f : 0], P.sg_npts[f < 3 ? f : 0], f, k); };
   static_assert(M_INTR == M_SG50 + 1, "mask order");
   for (int i = tid; i < 2 * NWORDS / 4; i += NT) reinterpret_cast<uint4*>(S.bm + M_SG50 * NWORDS)[i] = make_uint4(0u, 0u, 0u, 0u);
-  __syncthreads();  // phase 3c reads of T complete before B1 is recycled
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    *reinterpret_cast<float4*>(&S.B0[4 * (tid + NT * r)]) = make_float4(y[r][0], y[r][1], y[r][2], y[r][3]);
+  __syncthreads();  // B0 = y visible to every wave (halo and LS reads below)
   {
     float gmax = -INFINITY;
     WinAccF sgb = {0, 0, 0};   // pivot 0: the SG derivative of a baseline has no level
@@ -1283,7 +1062,242 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       S.outv[C_t50_current] = t50cur_us; S.outv[C_inTrace_intersect] = intr_x; S.outv[C_inTrace_n] = __int_as_float(intr_n);
     }
   }
+  if (P.dbg_stop == 2) return;
+
+  // ------------------------------------------------- phase 3: T = prefix sum of y
+  float pv_pz;
+  {
+    float tot[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i0 = 4 * (tid + NT * r);
+      tot[r] = (y[r][0] + y[r][1]) + (y[r][2] + y[r][3]);
+    }
+    double t_off[R], tot_all;
+    s4_exscan_sum<NT, R>(tot, t_off, part_buf(), &tot_all);   // barrier inside: the SG stage's reads of B1 are done
+    // signalstats of the pole-zero corrected tail (dsp_icpc.jl:122), pivot = its first sample
+    WinAccF pz = {0, 0, 0};
+    pv_pz = S.B0[P.tail.from];
+    const float ficp = (float)P.tail.ic;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i0 = 4 * (tid + NT * r);
+      winf_accum4(pz, P.tail, i0, (float)i0 - ficp, pv_pz, y[r][0], y[r][1], y[r][2], y[r][3]);
+      double run = t_off[r];
+      float4 t;
+      float* pt = &t.x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pt[e] = (float)run; run += (double)y[r][e]; }
+      *reinterpret_cast<float4*>(&S.B1[i0]) = t;
+    }
+    win_publish<NW>(pz, S.wsum, 6);
+    if (tid == 0) S.B1[Lp] = (float)tot_all;  // T[Lp] (= T[L] when L == Lp; y is 0 beyond L)
+    for (int i = tid; i < 7 * NWORDS / 4; i += NT)  // phase-3 mask words: only non-zero ballots are stored
+      reinterpret_cast<uint4*>(S.bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float tailmean, tailsigma, tailslope, tailoffset;
+    win_finish(win_collect<NW>(S.wsum, 6), P.tail, pv_pz, P.t_first, P.dt, &tailmean, &tailsigma, &tailslope, &tailoffset);
+    S.outv[C_tailmean] = tailmean; S.outv[C_tailsigma] = tailsigma; S.outv[C_tailslope] = tailslope; S.outv[C_tailoffset] = tailoffset;
+  }
+  if (P.dbg_stop == 3) return;
+
+  // ------------------------------------------------ phase 4: lane-strided sweep
+  const float thr_tx[5] = {e_max * 0.1f, e_max * 0.5f, e_max * 0.8f, e_max * 0.9f, e_max * 0.99f};
+  {
+    float mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY, mn0 = INFINITY, mn2 = INFINITY;
+    float bo_v = -INFINITY; int bo_i = 0x7fffffff;
+    const int nout_t0 = L - P.t0.flen + 1, nout_t0i = L - P.t0inv.flen + 1;
+    const int nout_f0 = L - P.fixed[0].flen + 1, nout_f1 = L - P.fixed[1].flen + 1,
+              nout_f2 = L - P.fixed[2].flen + 1, nout_opt = L - P.opt.flen + 1;
+    const TrapDev t0 = P.t0, t0i = P.t0inv, f0 = P.fixed[0], f1 = P.fixed[1], f2 = P.fixed[2], fo = P.opt;
+    const bool inv_same = P.t0inv_same != 0;
+    // One base register per shifted read; the row offset NT*m is an immediate.  A trapezoid is
+    // evaluated unscaled, o' = (T[k+flen]-T[k+n1+g])*(inv2/inv1) - (T[k+n1]-T[k]) (two subtractions and
+    // one fma), thresholds are divided by inv1 and maxima multiplied by it after the sweep.
+    // Rows wholly inside an output range skip the per-lane range test (scalar branch on the row).
+    const float* tb = &S.B1[tid];
+    auto traw = [&](const float* a, const float* b, const float* c, float rr, float Tk, int m) {
+      return fmaf(c[NT * m] - b[NT * m], rr, -(a[NT * m] - Tk));
+    };
+    // ---- sweep A: threshold bit-masks of y (5) and of the t0 trapezoid (2)
+    {
+      const float* yb = &S.B0[tid];
+      const float *t0a = tb + t0.n1, *t0b = tb + t0.n1 + t0.g, *t0c = tb + t0.flen;
+      const float *tia = tb + t0i.n1, *tib = tb + t0i.n1 + t0i.g, *tic = tb + t0i.flen;
+      const float rr0 = t0.rr, rri = t0i.rr;
+      const float thr0 = P.t0_thr * t0.navg, thr0i = -P.t0_thr * t0i.navg;
+#pragma unroll
+      for (int m = 0; m < SP; ++m) {
+        const int k = tid + NT * m;
+        float yv = yb[NT * m];
+        if (!FULL && NT * (m + 1) > L) yv = (k < L) ? yv : -INFINITY;
+        unsigned long long bq[7];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) bq[q] = __ballot(yv >= thr_tx[q]);
+        const float Tk = tb[NT * m];
+        float o0 = NAN, o0i = NAN;   // NaN: both comparisons false for rows/lanes outside the output range
+        if (NT * (m + 1) <= nout_t0) o0 = traw(t0a, t0b, t0c, rr0, Tk, m);
+        else if (NT * m < nout_t0) { o0 = traw(t0a, t0b, t0c, rr0, Tk, m); o0 = (k < nout_t0) ? o0 : NAN; }
+        if (inv_same) o0i = o0;
+        else if (NT * (m + 1) <= nout_t0i) o0i = traw(tia, tib, tic, rri, Tk, m);
+        else if (NT * m < nout_t0i) { o0i = traw(tia, tib, tic, rri, Tk, m); o0i = (k < nout_t0i) ? o0i : NAN; }
+        bq[M_T0] = __ballot(o0 >= thr0);
+        bq[M_T0INV] = __ballot(o0i <= thr0i);   // -trap >= thr
+        // the mask words were zeroed in phase 2: all-zero ballots (most rows of the t0 masks, the
+        // baseline rows of the y masks) are not stored.  thr_tx ascends, so bq[0] covers bq[1..4].
+        if (lane == 0) {
+          const int wb = (NT >> 5) * m + 2 * wave;
+          if (bq[0] | (e_max <= 0.f ? ~0ull : 0ull)) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) *reinterpret_cast<unsigned long long*>(&S.bm[q * NWORDS + wb]) = bq[q];
+          }
+          if (bq[M_T0]) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0 * NWORDS + wb]) = bq[M_T0];
+          if (bq[M_T0INV]) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0INV * NWORDS + wb]) = bq[M_T0INV];
+        }
+      }
+    }
+    // ---- sweep B: extrema of the three fixed trapezoids and the arg-max of the optimised one
+    {
+      const float *f0a = tb + f0.n1, *f0b = tb + f0.n1 + f0.g, *f0c = tb + f0.flen;
+      const float *f1a = tb + f1.n1, *f1b = tb + f1.n1 + f1.g, *f1c = tb + f1.flen;
+      const float *f2a = tb + f2.n1, *f2b = tb + f2.n1 + f2.g, *f2c = tb + f2.flen;
+      const float *foa = tb + fo.n1, *fob = tb + fo.n1 + fo.g, *foc = tb + fo.flen;
+      const float rr0 = f0.rr, rr1 = f1.rr, rr2 = f2.rr, rro = fo.rr;
+#pragma unroll
+      for (int m = 0; m < SP; ++m) {
+        const int k = tid + NT * m;
+        const float Tk = tb[NT * m];
+        if (NT * (m + 1) <= nout_f0) {
+          const float o = traw(f0a, f0b, f0c, rr0, Tk, m);
+          mx0 = vmax(mx0, o); mn0 = vmin(mn0, o);
+        } else if (NT * m < nout_f0) {
+          const float o = traw(f0a, f0b, f0c, rr0, Tk, m);
+          mx0 = vmax(mx0, (k < nout_f0) ? o : -INFINITY); mn0 = vmin(mn0, (k < nout_f0) ? o : INFINITY);
+        }
+        if (NT * (m + 1) <= nout_f1) mx1 = vmax(mx1, traw(f1a, f1b, f1c, rr1, Tk, m));
+        else if (NT * m < nout_f1) { const float o = traw(f1a, f1b, f1c, rr1, Tk, m); mx1 = vmax(mx1, (k < nout_f1) ? o : -INFINITY); }
+        if (NT * (m + 1) <= nout_f2) {
+          const float o = traw(f2a, f2b, f2c, rr2, Tk, m);
+          mx2 = vmax(mx2, o); mn2 = vmin(mn2, o);
+        } else if (NT * m < nout_f2) {
+          const float o = traw(f2a, f2b, f2c, rr2, Tk, m);
+          mx2 = vmax(mx2, (k < nout_f2) ? o : -INFINITY); mn2 = vmin(mn2, (k < nout_f2) ? o : INFINITY);
+        }
+        if (NT * (m + 1) <= nout_opt) {
+          const float o = traw(foa, fob, foc, rro, Tk, m);
+          if (o > bo_v) { bo_v = o; bo_i = k; }
+        } else if (NT * m < nout_opt) {
+          const float o = traw(foa, fob, foc, rro, Tk, m);
+          if (k < nout_opt && o > bo_v) { bo_v = o; bo_i = k; }
+        }
+      }
+      mx0 *= f0.inv1; mn0 *= f0.inv1; mx1 *= f1.inv1; mx2 *= f2.inv1; mn2 *= f2.inv1; bo_v *= fo.inv1;
+    }
+    mx0 = wave_max_all(mx0); mx1 = wave_max_all(mx1); mx2 = wave_max_all(mx2);
+    mn0 = wave_min_all(mn0); mn2 = wave_min_all(mn2);
+    unsigned long long bo = wave_max_u64(pack_vi(bo_v, bo_i));
+    if (lane == 0) {
+      atomicMax(&S.sl->fmx[FX_F0], ford(mx0));
+      atomicMax(&S.sl->fmx[FX_F1], ford(mx1));
+      atomicMax(&S.sl->fmx[FX_F2], ford(mx2));
+      // max(trap(-y)) = -min(trap(y)): negate BEFORE the order map (negating the decoded
+      // slot value was folded into a wrong sign by hipcc 7.2)
+      atomicMax(&S.sl->fmx[FX_F0I], ford(-mn0));
+      atomicMax(&S.sl->fmx[FX_F2I], ford(-mn2));
+      atomicMax(&S.sl->vi[VI_OPT], bo);
+    }
+  }
+  __syncthreads();
+  if (P.dbg_stop == 4) return;
+  // Intersect scans on the bit-masks (thread w <-> word w)
+  for (int j = tid; j < 7 * NWORDS; j += NT) {
+    const int q = j / NWORDS, wd = j - q * NWORDS;
+    const int min_n = (q < 5) ? P.tx_mintot : P.t0_mintot;
+    int c, f;
+    intersect_word(S.bm + q * NWORDS, wd, NWORDS, min_n, &c, &f);
+    if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + q], c); atomicMin(&S.sl->imin[q], f); }
+  }
+  __syncthreads();
+  {
+    float mx_opt_v; int mx_opt_i;
+    unpack_vi(S.sl->vi[VI_OPT], &mx_opt_v, &mx_opt_i);
+    put(C_e_trap_max, mx_opt_v); put(C_t_trap_max, P.t_first + P.dt * (float)(mx_opt_i + P.opt.flen - 1));
+    put(C_e_10410, ford_inv(S.sl->fmx[FX_F0])); put(C_e_535, ford_inv(S.sl->fmx[FX_F1])); put(C_e_313, ford_inv(S.sl->fmx[FX_F2]));
+    // trap(-y) = -trap(y)  (dsp_icpc.jl:199-204)
+    put(C_e_10410_inv, ford_inv(S.sl->fmx[FX_F0I])); put(C_e_313_inv, ford_inv(S.sl->fmx[FX_F2I]));
+  }
+  // crossing positions (sample units, split int + frac); NaN -> 0 us (dsp_routines.jl:24,41).
+  // Seven interpolations, one per lane (lane q < 5: threshold q of y; 5: t0; 6: inverted t0),
+  // evaluated once per wave and handed out by readlane.
+  Pos ptx[3];   // [1] = t50, [2] = t80 (the only ones used further down); pt0
+  Pos pt0;
+  {
+    const int q = min(lane, 6);
+    const bool has = S.sl->isum[IS_CNT0 + q] > 0;
+    const int p = S.sl->imin[q];
+    const float frac = (q == 0) ? 0.1f : (q == 1) ? 0.5f : (q == 2) ? 0.8f : (q == 3) ? 0.9f : 0.99f;
+    const float thr = (q < 5) ? e_max * frac : P.t0_thr;   // same products as thr_tx[]
+    Pos pp; pp.ip = 0; pp.fp = -P.t_first / P.dt;            // sample position of t = 0
+    float us = 0.f;
+    if (has) {
+      float yl, yh; int base;
+      if (q < 5) {
+        yl = S.B0[p - 1]; yh = S.B0[p]; base = p - 1;
+      } else {
+        const bool inv = (q == 6);
+        const TrapDev& t = (inv && !P.t0inv_same) ? P.t0inv : P.t0;
+        yl = trap_at(S.B1, p - 1, t); yh = trap_at(S.B1, p, t);
+        if (inv) { yl = -yl; yh = -yh; }
+        base = p - 1 + (t.flen - 1);  // trailing alignment (A1): back to input index space
+      }
+      pp.ip = base; pp.fp = (thr - yl) / (yh - yl);
+      us = (P.t_first + P.dt * ((float)base + pp.fp)) * P.inv_unit_per_us;
+    } else {
+      pp = pos_norm(pp);
+    }
+    ptx[1].ip = __builtin_amdgcn_readlane(pp.ip, 1); ptx[1].fp = readlane_f(pp.fp, 1);
+    ptx[2].ip = __builtin_amdgcn_readlane(pp.ip, 2); ptx[2].fp = readlane_f(pp.fp, 2);
+    pt0.ip = __builtin_amdgcn_readlane(pp.ip, 5); pt0.fp = readlane_f(pp.fp, 5);
+    if (wave == 0) {
+      if (lane < 7) S.outv[lane == 0 ? C_t10 : lane == 1 ? C_t50 : lane == 2 ? C_t80 : lane == 3 ? C_t90 : lane == 4 ? C_t99 : lane == 5 ? C_t0 : C_t0_inv] = us;
+      const float t90 = readlane_f(us, 3), t0u = readlane_f(us, 5);
+      if (lane == 0) S.outv[C_drift_time] = (t90 - t0u) * P.unit_per_us;
+    }
+  }
+  if (P.dbg_stop == 5) return;
+
+  // ------------------------------------------------ phase 3c: signal estimators
+  // e_trap = SignalEstimator(trap_opt output, t50 + rt + ft/2)     dsp_icpc.jl:163
+  // the seven estimates are spread over the waves (each needs a full wave: lane l = window point l)
+  {
+    float* eslot = S.misc + 4;
+    auto I = [&](int i) { return S.B1[i + 1]; };  // integrator output I[i] = T[i+1]  (dsp_routines.jl:53)
+    for (int e = wave; e < 7; e += NW) {
+      float v;
+      if (e == 0) {
+        Pos p = pos_add(ptx[1], P.trap_pickoff);
+        p.ip -= (P.opt.flen - 1);
+        v = estimate(P.sig_est, S.estB, p, L - P.opt.flen + 1, [&](int i) { return trap_at(S.B1, i, P.opt); });
+      } else if (e <= 3) {  // get_qdrift(wvfs, t0, qdrift_int_length)   dsp_routines.jl:51-64
+        const float d = (e == 1) ? 0.f : (e == 2 ? P.qdrift_d1 : P.qdrift_d2);
+        v = estimate(P.int_est, S.estB + EST_TBL, pos_add(pt0, d), L, I);
+      } else {              // lq: the same from t80 with lq_int_length      dsp_icpc.jl:144
+        const float d = (e == 4) ? 0.f : (e == 5 ? P.lq_d1 : P.lq_d2);
+        v = estimate(P.int_est, S.estB + EST_TBL, pos_add(ptx[2], d), L, I);
+      }
+      if (lane == 0) eslot[e] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      S.outv[C_e_trap] = eslot[0];
+      S.outv[C_qdrift] = (eslot[3] - eslot[2]) - (eslot[2] - eslot[1]);
+      S.outv[C_lq] = (eslot[6] - eslot[5]) - (eslot[5] - eslot[4]);
+    }
+  }
   if (P.dbg_stop == 6) return;
+
 
   if constexpr (FUSE) {
     // ------------------------------------------- phase 5: CUSP / ZAC (dsp_icpc.jl:167-178)
@@ -1292,7 +1306,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     for (int i = tid; i < pad; i += NT) S.B1[i - pad] = 0.f;  // the gap (dead mask words) becomes Dp[i < 0] = 0
     if (tid < 64) S.B1[Lp + tid] = 0.f;
     if (tid < 2) { S.sl->fmx[tid] = 0u; S.sl->imin[tid] = 0x7fffffff; }
-    cz_body<NT, R, FULL, false, true, true>(S, P, y, ptx[1], scan_buf);  // barriers inside order the above
+    cz_body<NT, R, FULL, false, true, true, true>(S, P, y, ptx[1], scan_buf);  // barriers inside order the above
   } else {
     // CUSP / ZAC run in icpc_cz_kernel; hand over blmean and the t50 position
     if (tid == 0) {
