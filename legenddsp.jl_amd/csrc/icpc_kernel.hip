@@ -1165,32 +1165,60 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       const float *f2a = tb + f2.n1, *f2b = tb + f2.n1 + f2.g, *f2c = tb + f2.flen;
       const float *foa = tb + fo.n1, *fob = tb + fo.n1 + fo.g, *foc = tb + fo.flen;
       const float rr0 = f0.rr, rr1 = f1.rr, rr2 = f2.rr, rro = fo.rr;
+      // Two rows per step: a pair's reads share their base registers (ds_read2st64_b32), its
+      // arithmetic packs (v_pk_add/fma) and one v_max3 / v_min3 folds both rows.  Pairs wholly
+      // inside an output range take the unmasked branch (scalar test); the one straddling pair
+      // of each trapezoid runs row by row with lane masks.
+      static_assert(SP % 2 == 0, "row pairs");
 #pragma unroll
-      for (int m = 0; m < SP; ++m) {
-        const int k = tid + NT * m;
-        const float Tk = tb[NT * m];
-        if (NT * (m + 1) <= nout_f0) {
-          const float o = traw(f0a, f0b, f0c, rr0, Tk, m);
-          mx0 = vmax(mx0, o); mn0 = vmin(mn0, o);
-        } else if (NT * m < nout_f0) {
-          const float o = traw(f0a, f0b, f0c, rr0, Tk, m);
-          mx0 = vmax(mx0, (k < nout_f0) ? o : -INFINITY); mn0 = vmin(mn0, (k < nout_f0) ? o : INFINITY);
+      for (int m = 0; m < SP; m += 2) {
+        const float Tk0 = tb[NT * m], Tk1 = tb[NT * (m + 1)];
+        auto row = [&](int mm) { return mm == m ? Tk0 : Tk1; };
+        if (NT * (m + 2) <= nout_f0) {
+          const float o0 = traw(f0a, f0b, f0c, rr0, Tk0, m), o1 = traw(f0a, f0b, f0c, rr0, Tk1, m + 1);
+          mx0 = vmax3(mx0, o0, o1); mn0 = vmin3(mn0, o0, o1);
+        } else {
+#pragma unroll
+          for (int mm = m; mm < m + 2; ++mm)
+            if (NT * mm < nout_f0) {
+              const float o = traw(f0a, f0b, f0c, rr0, row(mm), mm);
+              const bool in = tid + NT * mm < nout_f0;
+              mx0 = vmax(mx0, in ? o : -INFINITY); mn0 = vmin(mn0, in ? o : INFINITY);
+            }
         }
-        if (NT * (m + 1) <= nout_f1) mx1 = vmax(mx1, traw(f1a, f1b, f1c, rr1, Tk, m));
-        else if (NT * m < nout_f1) { const float o = traw(f1a, f1b, f1c, rr1, Tk, m); mx1 = vmax(mx1, (k < nout_f1) ? o : -INFINITY); }
-        if (NT * (m + 1) <= nout_f2) {
-          const float o = traw(f2a, f2b, f2c, rr2, Tk, m);
-          mx2 = vmax(mx2, o); mn2 = vmin(mn2, o);
-        } else if (NT * m < nout_f2) {
-          const float o = traw(f2a, f2b, f2c, rr2, Tk, m);
-          mx2 = vmax(mx2, (k < nout_f2) ? o : -INFINITY); mn2 = vmin(mn2, (k < nout_f2) ? o : INFINITY);
+        if (NT * (m + 2) <= nout_f1) {
+          mx1 = vmax3(mx1, traw(f1a, f1b, f1c, rr1, Tk0, m), traw(f1a, f1b, f1c, rr1, Tk1, m + 1));
+        } else {
+#pragma unroll
+          for (int mm = m; mm < m + 2; ++mm)
+            if (NT * mm < nout_f1) {
+              const float o = traw(f1a, f1b, f1c, rr1, row(mm), mm);
+              mx1 = vmax(mx1, (tid + NT * mm < nout_f1) ? o : -INFINITY);
+            }
         }
-        if (NT * (m + 1) <= nout_opt) {
-          const float o = traw(foa, fob, foc, rro, Tk, m);
-          if (o > bo_v) { bo_v = o; bo_i = k; }
-        } else if (NT * m < nout_opt) {
-          const float o = traw(foa, fob, foc, rro, Tk, m);
-          if (k < nout_opt && o > bo_v) { bo_v = o; bo_i = k; }
+        if (NT * (m + 2) <= nout_f2) {
+          const float o0 = traw(f2a, f2b, f2c, rr2, Tk0, m), o1 = traw(f2a, f2b, f2c, rr2, Tk1, m + 1);
+          mx2 = vmax3(mx2, o0, o1); mn2 = vmin3(mn2, o0, o1);
+        } else {
+#pragma unroll
+          for (int mm = m; mm < m + 2; ++mm)
+            if (NT * mm < nout_f2) {
+              const float o = traw(f2a, f2b, f2c, rr2, row(mm), mm);
+              const bool in = tid + NT * mm < nout_f2;
+              mx2 = vmax(mx2, in ? o : -INFINITY); mn2 = vmin(mn2, in ? o : INFINITY);
+            }
+        }
+        if (NT * (m + 2) <= nout_opt) {
+          const float o0 = traw(foa, fob, foc, rro, Tk0, m), o1 = traw(foa, fob, foc, rro, Tk1, m + 1);
+          if (o0 > bo_v) { bo_v = o0; bo_i = tid + NT * m; }
+          if (o1 > bo_v) { bo_v = o1; bo_i = tid + NT * (m + 1); }
+        } else {
+#pragma unroll
+          for (int mm = m; mm < m + 2; ++mm)
+            if (NT * mm < nout_opt) {
+              const float o = traw(foa, fob, foc, rro, row(mm), mm);
+              if (tid + NT * mm < nout_opt && o > bo_v) { bo_v = o; bo_i = tid + NT * mm; }
+            }
         }
       }
       mx0 *= f0.inv1; mn0 *= f0.inv1; mx1 *= f1.inv1; mx2 *= f2.inv1; mn2 *= f2.inv1; bo_v *= fo.inv1;
