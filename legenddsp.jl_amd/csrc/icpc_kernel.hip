@@ -867,6 +867,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     }
   }
   auto& y = x;
+  if (P.dbg_stop == 7) return;
 
   // ----------------------------------- phase 2: SG derivatives, current maxima
   // (runs before the prefix sum T is built: its full-length output is parked in B1, which T then
@@ -984,13 +985,14 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     }
     win_publish<NW>(sgb, S.wsum, 9);
     gmax = wave_max_all(gmax);
-    unsigned long long bk[4];
+    if (lane == 0) atomicMax(&S.sl->fmx[FX_G], ford(gmax));
+    // only the waves whose samples touch a current window hold a candidate (wave-uniform test)
 #pragma unroll
-    for (int f = 0; f < 4; ++f) bk[f] = wave_max_u64(pack_vi(bv[f], bi[f]));
-    if (lane == 0) {
-      atomicMax(&S.sl->fmx[FX_G], ford(gmax));
-#pragma unroll
-      for (int f = 0; f < 4; ++f) atomicMax(&S.sl->vi[VI_CUR0 + f], bk[f]);
+    for (int f = 0; f < 4; ++f) {
+      if (__ballot(bi[f] != 0x7fffffff) != 0ull) {
+        const unsigned long long bk = wave_max_u64(pack_vi(bv[f], bi[f]));
+        if (lane == 0) atomicMax(&S.sl->vi[VI_CUR0 + f], bk);
+      }
     }
   }
   __syncthreads();

@@ -8,7 +8,7 @@ p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, L, 0.0
 wf = ldsp.synth.hpge_batch(n, L, device="cuda")
 ctx = ldsp.default_context(); ctx.enable_timing(True)
 prev = 0
-for stop in (1, 2, 3, 4, 5, 6):
+for stop in (1, 7, 2, 3, 4, 5, 6):
     ctx.set_option("dbg_stop", stop)
     ldsp.icpc_run(wf, p, ctx); torch.cuda.synchronize()
     ms = min((ldsp.icpc_run(wf, p, ctx), ctx.last_kernel_ms())[1] for _ in range(3))
