@@ -666,8 +666,7 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
   }
   __syncthreads();
   cz_body<NT, R, FULL, DIRECT, WANT_C, WANT_Z, false>(S, P, y, ptx[1], scan_buf);
-  __syncthreads();
-  if (tid < 6) {
+  if (tid < 6) {  // S.outv: stored and read by wave 0
     const int cols[6] = {C_e_cusp, C_e_zac, C_e_cusp_max, C_e_zac_max, C_t_cusp_max, C_t_zac_max};
     const int c = cols[tid];
     const bool mine = (tid & 1) ? WANT_Z : WANT_C;
@@ -1032,38 +1031,9 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       if (bin) *reinterpret_cast<unsigned long long*>(&S.bm[M_INTR * NWORDS + wb]) = bin;
     }
   }
-  __syncthreads();
-  if (tid < NWORDS) {
-    int c, f;
-    intersect_word(S.bm + M_SG50 * NWORDS, tid, NWORDS, P.tx_mintot, &c, &f);
-    if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + M_SG50], c); atomicMin(&S.sl->imin[M_SG50], f); }
-    intersect_word_rev(S.bm + M_INTR * NWORDS, tid, NWORDS, ng, P.intrace_mintot, &c, &f);
-    if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + M_INTR], c); atomicMax(&S.sl->imax[0], f); }
-  }
-  __syncthreads();
-  // crossing interpolations: wave 0, lanes 0..3 evaluate the four SG samples they need
-  if (wave == 0) {
-    const int intr_n = S.sl->isum[IS_CNT0 + M_INTR];
-    const bool has50 = S.sl->isum[IS_CNT0 + M_SG50] > 0;
-    const int p = S.sl->imin[M_SG50], e = S.sl->imax[0];
-    const int at = (lane == 0) ? p - 1 : (lane == 1) ? p : (lane == 2) ? e + 1 : e;
-    float ev = 0.f;
-    if (lane < 4 && ((lane < 2) ? has50 : intr_n > 0)) ev = flt_rare(0, at);
-    const float yl5 = __shfl(ev, 0), yh5 = __shfl(ev, 1), yli = __shfl(ev, 2), yhi = __shfl(ev, 3);
-    if (lane == 0) {
-      const float tg_first = P.t_first + P.dt * (float)(P.sg_npts[0] - 1);  // trailing alignment (A1)
-      float t50cur_us = 0.f, intr_x = NAN;
-      if (has50) t50cur_us = (tg_first + P.dt * ((float)(p - 1) + (thr_sg50 - yl5) / (yh5 - yl5))) * P.inv_unit_per_us;
-      if (intr_n > 0) {
-        // reversed index pos' = ng-1-e ; r[pos'-1] = g[e+1], r[pos'] = g[e]
-        const int pr = ng - 1 - e;
-        const float xl = tg_first + P.dt * (float)(pr - 1);
-        const float xr_ = (thr_intr - yli) * P.dt / (yhi - yli) + xl;
-        intr_x = (tg_first + P.dt * (float)(ng - 1)) - xr_;  // last(time) - x   (dsp_routines.jl:81)
-      }
-      S.outv[C_t50_current] = t50cur_us; S.outv[C_inTrace_intersect] = intr_x; S.outv[C_inTrace_n] = __int_as_float(intr_n);
-    }
-  }
+  // (the run scans of these two masks and the crossing interpolations follow in phase 4b, together with
+  //  the seven masks of the sweep: no barrier here — the next one is inside the prefix-sum scan, which
+  //  also orders these B1 reads before T overwrites B1)
   if (P.dbg_stop == 2) return;
 
   // ------------------------------------------------- phase 3: T = prefix sum of y
@@ -1241,7 +1211,8 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   }
   __syncthreads();
   if (P.dbg_stop == 4) return;
-  // Intersect scans on the bit-masks (thread w <-> word w)
+  // Intersect scans on the bit-masks (thread w <-> word w): the seven masks of the sweep and the two
+  // of the SG stage (phase 2)
   for (int j = tid; j < 7 * NWORDS; j += NT) {
     const int q = j / NWORDS, wd = j - q * NWORDS;
     const int min_n = (q < 5) ? P.tx_mintot : P.t0_mintot;
@@ -1249,7 +1220,37 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     intersect_word(S.bm + q * NWORDS, wd, NWORDS, min_n, &c, &f);
     if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + q], c); atomicMin(&S.sl->imin[q], f); }
   }
+  for (int wd = tid; wd < NWORDS; wd += NT) {
+    int c, f;
+    intersect_word(S.bm + M_SG50 * NWORDS, wd, NWORDS, P.tx_mintot, &c, &f);
+    if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + M_SG50], c); atomicMin(&S.sl->imin[M_SG50], f); }
+    intersect_word_rev(S.bm + M_INTR * NWORDS, wd, NWORDS, ng, P.intrace_mintot, &c, &f);
+    if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + M_INTR], c); atomicMax(&S.sl->imax[0], f); }
+  }
   __syncthreads();
+  // crossing interpolations: wave 0, lanes 0..3 evaluate the four SG samples they need
+  if (wave == 0) {
+    const int intr_n = S.sl->isum[IS_CNT0 + M_INTR];
+    const bool has50 = S.sl->isum[IS_CNT0 + M_SG50] > 0;
+    const int p = S.sl->imin[M_SG50], e = S.sl->imax[0];
+    const int at = (lane == 0) ? p - 1 : (lane == 1) ? p : (lane == 2) ? e + 1 : e;
+    float ev = 0.f;
+    if (lane < 4 && ((lane < 2) ? has50 : intr_n > 0)) ev = flt_rare(0, at);
+    const float yl5 = __shfl(ev, 0), yh5 = __shfl(ev, 1), yli = __shfl(ev, 2), yhi = __shfl(ev, 3);
+    if (lane == 0) {
+      const float tg_first = P.t_first + P.dt * (float)(P.sg_npts[0] - 1);  // trailing alignment (A1)
+      float t50cur_us = 0.f, intr_x = NAN;
+      if (has50) t50cur_us = (tg_first + P.dt * ((float)(p - 1) + (thr_sg50 - yl5) / (yh5 - yl5))) * P.inv_unit_per_us;
+      if (intr_n > 0) {
+        // reversed index pos' = ng-1-e ; r[pos'-1] = g[e+1], r[pos'] = g[e]
+        const int pr = ng - 1 - e;
+        const float xl = tg_first + P.dt * (float)(pr - 1);
+        const float xr_ = (thr_intr - yli) * P.dt / (yhi - yli) + xl;
+        intr_x = (tg_first + P.dt * (float)(ng - 1)) - xr_;  // last(time) - x   (dsp_routines.jl:81)
+      }
+      S.outv[C_t50_current] = t50cur_us; S.outv[C_inTrace_intersect] = intr_x; S.outv[C_inTrace_n] = __int_as_float(intr_n);
+    }
+  }
   {
     float mx_opt_v; int mx_opt_i;
     unpack_vi(S.sl->vi[VI_OPT], &mx_opt_v, &mx_opt_i);
@@ -1331,7 +1332,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
 
   if constexpr (FUSE) {
     // ------------------------------------------- phase 5: CUSP / ZAC (dsp_icpc.jl:167-178)
-    __syncthreads();  // every phase-4 read of the mask words, the SG output and the slots is done
+    // (behind the estimators' barrier: nobody reads the mask words, B1[Lp..] or slots 0..1 any more)
     const int pad = cz_pad(P);
     for (int i = tid; i < pad; i += NT) S.B1[i - pad] = 0.f;  // the gap (dead mask words) becomes Dp[i < 0] = 0
     if (tid < 64) S.B1[Lp + tid] = 0.f;
@@ -1346,7 +1347,8 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     }
   }
   // ---------------------------------------------------------------- outputs
-  __syncthreads();
+  // every S.outv entry was stored by a lane of wave 0 and is read here by wave 0: program order suffices
+  static_assert(C_NCOLS <= 64, "the output row is stored by wave 0");
   if (tid < C_NCOLS) {
     const bool cz_col = tid == C_e_cusp || tid == C_e_zac || tid == C_e_cusp_max || tid == C_e_zac_max ||
                         tid == C_t_cusp_max || tid == C_t_zac_max;
