@@ -31,6 +31,7 @@ struct SipmDev {
   ldsp_trap trap;
   int32_t trap_mintot, trap_maxtot;
   float trap_min_thr, trap_max_thr, trap_nsigma, trap_min_dc, trap_max_dc, trap_nsigma_dc;
+  int32_t dbg_stop;  // profiling aid: return after stage k (tools/gpu_time_sipm.py)
 };
 
 enum { S_t_max, S_t_min, S_t_max_lar, S_t_min_lar, S_e_max, S_e_min, S_e_max_lar, S_e_min_lar,
@@ -72,6 +73,7 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
     put(S_e_min_lar, vmin); put(S_e_max_lar, vmax);
     put(S_t_min_lar, (P.t_first + P.dt * (float)imin) * P.inv_upus); put(S_t_max_lar, (P.t_first + P.dt * (float)imax) * P.inv_upus);
   }
+  if (P.dbg_stop == 1) return;
   // SavitzkyGolayFilter(wl, degree, 1): g -> B   :99-100   (valid mode, trailing time axis, A1)
   const int np = P.np, ng = L - np + 1;
   const float tg = P.t_first + P.dt * (float)(np - 1);
@@ -81,9 +83,13 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
     B[k] = g;
   }
   __syncthreads();
+  if (P.dbg_stop == 2) return;
   // SG triggers :103-105
-  const float thr_sg = tb::mad_threshold(B, ng, P.sg_min_thr, P.sg_max_thr, 1.f, sc);
+  // (A = x is dead from here to the InvCR stage: it serves as the radix select's candidate buffer)
+  uint32_t* cand = reinterpret_cast<uint32_t*>(A);
+  const float thr_sg = tb::mad_threshold(B, ng, P.sg_min_thr, P.sg_max_thr, 1.f, sc, cand, pad4(L));
   put(S_threshold, thr_sg);
+  if (P.dbg_stop == 3) return;
   {
     const float th = P.sg_nsigma * thr_sg;
     tb::build_mask(B, ng, 1.f, th, bm);
@@ -98,6 +104,7 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
     if (tid == 0 && o.count) o.count[b] = tot;
   }
   __syncthreads();
+  if (P.dbg_stop == 4) return;
   const float minx = fminf(sc.f[1], 0.f);
   // IntegratorFilter(gain = 1): I = cumsum(g) in place   :108-109
   tb::prefix_sum_inplace(B, ng, sc);
@@ -112,12 +119,13 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
     tb::window_stats<false>(B, 0, ng - 1, tg, P.dt, sc, &m, &sg, &sl, &of);
     put(S_wfmean, m); put(S_wfsigma, sg); put(S_wfslope, sl); put(S_wfoffset, of);
   }
+  if (P.dbg_stop == 5) return;
   // discharge detection on the flipped integrated trace (-I): SG and trap bounds, both with
   // the SG IntersectMaximum functor   :118-120, :137-138
   for (int v = 0; v < 2; ++v) {
     const float lo = v ? P.trap_min_dc : P.sg_min_dc, hi = v ? P.trap_max_dc : P.sg_max_dc;
     const float ns = v ? P.trap_nsigma_dc : P.sg_nsigma_dc;
-    const float thr = tb::mad_threshold(B, ng, lo, hi, -1.f, sc);
+    const float thr = tb::mad_threshold(B, ng, lo, hi, -1.f, sc, cand, pad4(L));
     put(v ? S_threshold_DC_trap : S_threshold_DC, thr);
     const float th = ns * thr;
     tb::build_mask(B, ng, -1.f, th, bm);
@@ -130,6 +138,7 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
     if (tid == 0 && o.count) o.count[b] = tot;
     __syncthreads();
   }
+  if (P.dbg_stop == 6) return;
   // InvCRFilter(pz_tau) on I, then TrapezoidalChargeFilter(rt, ft)   :124-129
   for (int i = tid; i < pad4(L); i += NT) A[i] = (i < ng) ? B[i] : 0.f;
   __syncthreads();
@@ -165,8 +174,9 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
     }
   }
   __syncthreads();
+  if (P.dbg_stop == 7) return;
   // trap triggers :132-134
-  const float thr_t = tb::mad_threshold(B, nt, P.trap_min_thr, P.trap_max_thr, 1.f, sc);
+  const float thr_t = tb::mad_threshold(B, nt, P.trap_min_thr, P.trap_max_thr, 1.f, sc, cand, pad4(L));  // A = P is dead
   put(S_threshold_trap, thr_t);
   {
     const float th = P.trap_nsigma * thr_t;
@@ -213,6 +223,7 @@ extern "C" int ldsp_sipm_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp
   d.pz_c = (float)p->pz_c; d.trap = p->trap;
   d.trap_mintot = p->trap_mintot; d.trap_maxtot = p->trap_maxtot;
   d.trap_min_thr = (float)p->trap_min_thr; d.trap_max_thr = (float)p->trap_max_thr; d.trap_nsigma = (float)p->trap_nsigma;
+  d.dbg_stop = c->dbg_stop;
   d.trap_min_dc = (float)p->trap_min_dc_thr; d.trap_max_dc = (float)p->trap_max_dc_thr; d.trap_nsigma_dc = (float)p->trap_nsigma_dc;
   sipm::SipmOutDev od;
   static_assert(sizeof(ldsp_sipm_out) == sizeof(void*) * sipm::S_NCOLS + 4 * sizeof(ldsp_trig_out), "ldsp_sipm_out layout");
@@ -227,6 +238,6 @@ extern "C" int ldsp_sipm_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp
   hipLaunchKernelGGL(sipm::k_sipm, dim3((unsigned)n), dim3(nt), bytes, c->stream, wf, d, od);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ldsp_fail(LDSP_ERR_HIP, "launch: %s", hipGetErrorString(e));
-  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; }
+  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
   return LDSP_OK;
 }

@@ -15,9 +15,11 @@ namespace tb {
 struct Scratch {           // small LDS work area shared by the blocks below
   double d[3 * 16];        // per-wave partials
   unsigned long long u64[2];
-  uint32_t hist[256];      // radix-select histogram
+  uint32_t hist[2048];     // radix-select histogram (11-bit digits)
   int i[8];
   float f[8];
+  int wtot[16];            // per-wave totals of block scans
+  uint32_t u32min;
 };
 
 __device__ __forceinline__ int nwaves() { return blockDim.x >> 6; }
@@ -208,82 +210,255 @@ __device__ __forceinline__ float window_max_interp(const float* s, int from, int
   return v;
 }
 
-// ---- order statistics by radix select ----------------------------------------------
-// KEY(i) -> (valid, 32-bit ordered key).  Returns the key of rank k (0-based) among
-// the valid elements; 4 passes of 8 bits, histogram by LDS atomics.
-template <typename KEY>
-__device__ __forceinline__ uint32_t radix_select(int n, int k, KEY key, Scratch& sc) {
+// ---- order statistics ----------------------------------------------------------------
+// Exact selection (rank k of the valid elements, plus rank k+1 for even counts) in two levels:
+//   level 1: ONE histogram pass over the trace that isolates a small candidate set, written to
+//            an LDS list — by linear bins around (mean +- 4 sigma) when the caller has those
+//            (median_linear: a noise trace then spreads over ~2000 bins and the LDS atomics are
+//            nearly conflict-free; measured 4.6 clk per wave-atomic conflict-free vs 30 clk at
+//            8 lanes per address, tools/micro/lds_atomic_test.hip), or by the top 11 bits of the
+//            ordered key (radix_select: always applicable);
+//   level 2: three radix passes (11 + 11 + 10 bits) over the candidate list only.
+// Histogram bin location: every thread owns nbins/NT consecutive bins, block-wide scan.
+
+// after a histogram of `nbins` bins sits in sc.hist: bin holding rank k -> sc.i[4], rank inside
+// it -> sc.i[5], its population -> sc.i[6].  Barrier before (hist complete) is the caller's.
+__device__ __forceinline__ void locate_bin(const uint32_t* hist, int nbins, int k, Scratch& sc) {
   const int tid = threadIdx.x, NT = blockDim.x;
-  uint32_t prefix = 0, mask = 0;
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int b = tid; b < 256; b += NT) sc.hist[b] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += NT) {
-      bool valid; uint32_t kv;
-      key(i, &valid, &kv);
-      if (valid && (kv & mask) == prefix) atomicAdd(&sc.hist[(kv >> shift) & 255u], 1u);
-    }
-    __syncthreads();
-    if (tid < 64) {  // wave 0: find the bin that contains rank k
-      uint32_t c0 = sc.hist[4 * tid], c1 = sc.hist[4 * tid + 1], c2 = sc.hist[4 * tid + 2], c3 = sc.hist[4 * tid + 3];
-      int tot = (int)(c0 + c1 + c2 + c3);
-      int inc = wave_incl_scan_sum_i(tot);
-      int exc = inc - tot;
-      if (k >= exc && k < inc) {
-        int r = k - exc, b = 4 * tid;
-        if (r >= (int)c0) { r -= c0; ++b; if (r >= (int)c1) { r -= c1; ++b; if (r >= (int)c2) { r -= c2; ++b; } } }
-        sc.i[4] = b; sc.i[5] = r;
-      }
-    }
-    __syncthreads();
-    prefix |= ((uint32_t)sc.i[4]) << shift;
-    mask |= 0xffu << shift;
-    k = sc.i[5];
-    __syncthreads();
+  const int per = (nbins + NT - 1) / NT, b0 = per * tid;
+  int tot = 0;
+  for (int q = 0; q < per; ++q) if (b0 + q < nbins) tot += (int)hist[b0 + q];
+  const int inc = wave_incl_scan_sum_i(tot);
+  if ((tid & 63) == 63) sc.wtot[tid >> 6] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < (tid >> 6); ++w) base += sc.wtot[w];
+  const int exc = base + inc - tot;
+  if (tot > 0 && k >= exc && k < exc + tot) {   // exactly one thread
+    int r = k - exc, b = b0;
+    while (r >= (int)hist[b]) { r -= (int)hist[b]; ++b; }
+    sc.i[4] = b; sc.i[5] = r; sc.i[6] = (int)hist[b];
   }
-  return prefix;
+  __syncthreads();
+}
+// One histogram pass over `cnt` items: GET(j) -> (valid, 32-bit ordered key).  Among the valid
+// keys with (key & mask) == prefix, finds the `nbins`-way digit (key >> shift) & (nbins-1) that
+// holds rank k; k becomes the rank inside that digit, cnt_in the digit's population.
+template <typename GET>
+__device__ __forceinline__ void radix_pass(int cnt, GET get, uint32_t mask, uint32_t prefix, int shift, int nbins, int* k,
+                                           uint32_t* digit, int* cnt_in, Scratch& sc) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  for (int b = tid; b < nbins; b += NT) sc.hist[b] = 0;
+  __syncthreads();
+  for (int j = tid; j < cnt; j += NT) {
+    bool valid; uint32_t kv;
+    get(j, &valid, &kv);
+    if (valid && (kv & mask) == prefix) atomicAdd(&sc.hist[(kv >> shift) & (uint32_t)(nbins - 1)], 1u);
+  }
+  __syncthreads();
+  locate_bin(sc.hist, nbins, *k, sc);
+  *digit = (uint32_t)sc.i[4]; *k = sc.i[5]; *cnt_in = sc.i[6];
+  __syncthreads();
+}
+// append the keys selected by PRED(i) -> (take, key) for i < n to list[] (order irrelevant):
+// wave-aggregated, one LDS atomic per wave and row.  The count is known to the caller.
+template <typename PRED>
+__device__ __forceinline__ void compact_keys(int n, PRED pred, uint32_t* list, Scratch& sc) {
+  const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
+  if (tid == 0) sc.i[7] = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += NT) {
+    const int i = base + tid;
+    bool take = false; uint32_t kv = 0;
+    if (i < n) pred(i, &take, &kv);
+    const unsigned long long m = __ballot(take);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      int pos = 0;
+      if (lane == leader) pos = atomicAdd(&sc.i[7], __popcll(m));
+      pos = __builtin_amdgcn_readlane(pos, leader);
+      if (take) list[pos + __popcll(m & ((1ull << lane) - 1ull))] = kv;
+    }
+  }
+  __syncthreads();
+}
+// rank k of list[0..cnt) (all 32 key bits); *has_next / *next: the key of rank k+1 if it is in the list
+__device__ __forceinline__ uint32_t select_in_list(const uint32_t* list, int cnt, int k, Scratch& sc, bool want_next, bool* has_next,
+                                                   uint32_t* next) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  auto kc = [&](int j, bool* valid, uint32_t* kv) { *valid = true; *kv = list[j]; };
+  uint32_t d1, d2, d3;
+  int c1, c2, c3;
+  const bool last_of_list = (k == cnt - 1);
+  radix_pass(cnt, kc, 0u, 0u, 21, 2048, &k, &d1, &c1, sc);
+  radix_pass(cnt, kc, 0x7ffu << 21, d1 << 21, 10, 2048, &k, &d2, &c2, sc);
+  radix_pass(cnt, kc, 0xfffffc00u, (d1 << 21) | (d2 << 10), 0, 1024, &k, &d3, &c3, sc);
+  const uint32_t kk = (d1 << 21) | (d2 << 10) | d3;
+  if (want_next) {
+    if (k + 1 < c3) {            // c3 keys equal kk, k = rank among them
+      *has_next = true; *next = kk;
+    } else if (last_of_list) {
+      *has_next = false;
+    } else {                     // the smallest key of the list above kk
+      if (tid == 0) sc.u32min = 0xffffffffu;
+      __syncthreads();
+      uint32_t mn = 0xffffffffu;
+      for (int j = tid; j < cnt; j += NT) { const uint32_t kv = list[j]; if (kv > kk) mn = min(mn, kv); }
+      if (mn != 0xffffffffu) atomicMin(&sc.u32min, mn);
+      __syncthreads();
+      *has_next = true; *next = sc.u32min;
+      __syncthreads();
+    }
+  }
+  return kk;
+}
+// the smallest valid key above kk over the whole trace (rank k+1 when it falls outside the candidate list)
+template <typename KEY>
+__device__ __forceinline__ uint32_t next_key_above(int n, KEY key, uint32_t kk, Scratch& sc) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  if (tid == 0) sc.u32min = 0xffffffffu;
+  __syncthreads();
+  uint32_t mn = 0xffffffffu;
+  for (int i = tid; i < n; i += NT) {
+    bool valid; uint32_t kv;
+    key(i, &valid, &kv);
+    if (valid && kv > kk) mn = min(mn, kv);
+  }
+  if (mn != 0xffffffffu) atomicMin(&sc.u32min, mn);
+  __syncthreads();
+  const uint32_t r = sc.u32min;
+  __syncthreads();
+  return r;
+}
+// KEY(i) -> (valid, 32-bit ordered key) for i < n.  Returns the key of rank k (0-based) among the
+// valid elements; `next` (optional) receives the key of rank k+1 (the caller guarantees it exists).
+// `list`: n words of LDS that are free at the call, or nullptr (then three passes over the trace).
+template <typename KEY>
+__device__ __forceinline__ uint32_t radix_select(int n, int k, KEY key, Scratch& sc, uint32_t* list, uint32_t* next = nullptr) {
+  uint32_t d1, d2, d3;
+  int c1, c2, c3;
+  radix_pass(n, key, 0u, 0u, 21, 2048, &k, &d1, &c1, sc);
+  uint32_t kk;
+  bool has_next = false;
+  if (list) {
+    compact_keys(n, [&](int i, bool* take, uint32_t* kv) { bool v; key(i, &v, kv); *take = v && (*kv >> 21) == d1; }, list, sc);
+    kk = select_in_list(list, c1, k, sc, next != nullptr, &has_next, next);
+  } else {
+    radix_pass(n, key, 0x7ffu << 21, d1 << 21, 10, 2048, &k, &d2, &c2, sc);
+    radix_pass(n, key, 0xfffffc00u, (d1 << 21) | (d2 << 10), 0, 1024, &k, &d3, &c3, sc);
+    kk = (d1 << 21) | (d2 << 10) | d3;
+    if (next && k + 1 < c3) { *next = kk; has_next = true; }
+  }
+  if (next && !has_next) *next = next_key_above(n, key, kk, sc);
+  return kk;
 }
 // Statistics.median over the valid elements: mean of the two middle order statistics for
 // even counts.  m = number of valid elements (> 0).
 template <typename KEY>
-__device__ __forceinline__ float median_valid(int n, int m, KEY key, Scratch& sc) {
-  const int tid = threadIdx.x, NT = blockDim.x;
+__device__ __forceinline__ float median_valid(int n, int m, KEY key, Scratch& sc, uint32_t* list) {
   const int k = (m - 1) >> 1;
-  const uint32_t kk = radix_select(n, k, key, sc);
+  uint32_t nxt = 0;
+  const uint32_t kk = radix_select(n, k, key, sc, list, (m & 1) ? nullptr : &nxt);
   const float lo = ford_inv(kk);
   if (m & 1) return lo;
-  // next order statistic: equal to lo if enough duplicates, else the smallest key above
-  int cle = 0;
-  uint32_t nxt = 0xffffffffu;
-  for (int i = tid; i < n; i += NT) {
-    bool valid; uint32_t kv;
-    key(i, &valid, &kv);
-    if (valid) { cle += (kv <= kk); if (kv > kk) nxt = min(nxt, kv); }
-  }
-  cle = blk_sum_i(cle, sc);
-  const int nx = blk_min_i((int)(nxt ^ 0x80000000u), sc);  // unsigned order via sign flip
-  const float hi = (cle >= k + 2) ? lo : ford_inv(((uint32_t)nx) ^ 0x80000000u);
-  return 0.5f * (lo + hi);
+  return 0.5f * (lo + ford_inv(nxt));
 }
-// thresholdstats_mad (src/thresholdstats.jl:61-71): 1.4826 * median(|y - median(y)|) over lo <= y <= hi
-__device__ __forceinline__ float mad_threshold(const float* s, int n, float lo, float hi, float scale_sign, Scratch& sc) {
+// rank r (and r+1) among list[0..cnt), cnt <= 64, by every wave on its own: lane j holds key j and
+// counts the keys that sort before it (ties by position); no LDS writes, no barrier.
+__device__ __forceinline__ uint32_t select_small(const uint32_t* list, int cnt, int r, bool* has_next, uint32_t* next) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t mine = (lane < cnt) ? list[lane] : 0xffffffffu;
+  int rank = 0;
+  for (int i = 0; i < cnt; ++i) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)mine, i);
+    rank += (o < mine) || (o == mine && i < lane);
+  }
+  const unsigned long long mr = __ballot(lane < cnt && rank == r), mn = __ballot(lane < cnt && rank == r + 1);
+  const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)mr) - 1);
+  *has_next = mn != 0ull;
+  if (mn) *next = (uint32_t)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)mn) - 1);
+  return kk;
+}
+// The same median with a linear first level: VAL(i) -> (valid, value); NB bins of width 1/scale from `a`
+// (NB = 2048 .. 8192, as many as the work area allows: a trace of noise then leaves a handful of
+// candidates in the median's bin and the second level runs inside a wave).  work: nwork words of
+// free LDS, split into histogram and candidate list.  Returns false (nothing computed) when a needed
+// rank falls outside the binned range — the caller then uses median_valid.  Binning is monotone in
+// the value, so the selection stays exact.
+template <typename VAL>
+__device__ __forceinline__ bool median_linear(int n, int m, VAL val, float a, float sd_span, Scratch& sc, uint32_t* work, int nwork,
+                                              float* med) {
+  const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
+  const int NB = (nwork >= 16384) ? 8192 : (nwork >= 8192 ? 4096 : 2048);
+  uint32_t* hist = (nwork >= 4096) ? work : sc.hist;
+  uint32_t* list = (nwork >= 4096) ? work + NB : work;
+  const float scale = (float)NB / sd_span;
+  for (int b = tid; b < NB; b += NT) hist[b] = 0;
+  if (tid == 0) { sc.i[2] = 0; sc.i[3] = 0; }
+  __syncthreads();
+  auto bin_of = [&](float v) -> int {   // -1 below, NB above (also NaN)
+    const float t = (v - a) * scale;
+    return (t < 0.f) ? -1 : (t < (float)NB ? (int)t : NB);
+  };
+  for (int base = 0; base < n; base += NT) {
+    const int i = base + tid;
+    bool valid = false; float v = 0.f;
+    if (i < n) val(i, &valid, &v);
+    const int b = valid ? bin_of(v) : 0;
+    if (valid && b >= 0 && b < NB) atomicAdd(&hist[b], 1u);
+    const unsigned long long mu = __ballot(valid && b < 0), mo = __ballot(valid && b >= NB);
+    if (lane == 0) {
+      if (mu) atomicAdd(&sc.i[2], __popcll(mu));
+      if (mo) atomicAdd(&sc.i[3], __popcll(mo));
+    }
+  }
+  __syncthreads();
+  const int k = (m - 1) >> 1, need = (m & 1) ? 0 : 1;
+  const int cu = sc.i[2], co = sc.i[3];
+  if (k < cu || k + need >= m - co) return false;   // block-uniform
+  locate_bin(hist, NB, k - cu, sc);
+  const int bsel = sc.i[4], r = sc.i[5], cb = sc.i[6];
+  __syncthreads();
+  if (cb > ((nwork >= 4096) ? nwork - NB : nwork)) return false;   // (block-uniform) heavily clustered values: the list would not fit
+  compact_keys(n, [&](int i, bool* take, uint32_t* kv) { bool v; float x; val(i, &v, &x); *take = v && bin_of(x) == bsel; *kv = ford(x); }, list, sc);
+  bool has_next = false;
+  uint32_t nxt = 0, kk;
+  if (cb <= 64) kk = select_small(list, cb, r, &has_next, &nxt);
+  else kk = select_in_list(list, cb, r, sc, need != 0, &has_next, &nxt);
+  const float lo = ford_inv(kk);
+  if (!need) { *med = lo; return true; }
+  if (!has_next) nxt = next_key_above(n, [&](int i, bool* v, uint32_t* kv) { float x; val(i, v, &x); *kv = ford(x); }, kk, sc);
+  *med = 0.5f * (lo + ford_inv(nxt));
+  return true;
+}
+// thresholdstats_mad (src/thresholdstats.jl:61-71): 1.4826 * median(|y - median(y)|) over lo <= y <= hi.
+// work: nwork >= n words of free LDS (or nullptr: three radix passes over the trace per median)
+__device__ __forceinline__ float mad_threshold(const float* s, int n, float lo, float hi, float scale_sign, Scratch& sc,
+                                               uint32_t* work = nullptr, int nwork = 0) {
+  uint32_t* list = work;
   const int tid = threadIdx.x, NT = blockDim.x;
-  int m = 0;
-  for (int i = tid; i < n; i += NT) { const float y = scale_sign * s[i]; m += (lo <= y && y <= hi); }
-  m = blk_sum_i(m, sc);
+  // count, mean and spread of the valid samples (the spread only steers the binning)
+  double v[3] = {0, 0, 0};
+  for (int i = tid; i < n; i += NT) {
+    const float y = scale_sign * s[i];
+    if (lo <= y && y <= hi) { v[0] += 1.0; v[1] += (double)y; v[2] = fma((double)y, (double)y, v[2]); }
+  }
+  blk_sum3(v, sc);
+  const int m = (int)v[0];
   if (m == 0) return 0.f;
-  auto k1 = [&](int i, bool* valid, uint32_t* kv) {
-    const float y = scale_sign * s[i];
-    *valid = (lo <= y && y <= hi);
-    *kv = ford(y);
-  };
-  const float med = median_valid(n, m, k1, sc);
-  auto k2 = [&](int i, bool* valid, uint32_t* kv) {
-    const float y = scale_sign * s[i];
-    *valid = (lo <= y && y <= hi);
-    *kv = ford(fabsf(y - med));
-  };
-  return 1.4826f * median_valid(n, m, k2, sc);
+  const float mean = (float)(v[1] / v[0]);
+  const double var = v[2] / v[0] - (v[1] / v[0]) * (v[1] / v[0]);
+  const float sd = var > 0 ? (float)sqrt(var) : 0.f;
+  auto v1 = [&](int i, bool* valid, float* x) { const float y = scale_sign * s[i]; *valid = (lo <= y && y <= hi); *x = y; };
+  auto k1 = [&](int i, bool* valid, uint32_t* kv) { float x; v1(i, valid, &x); *kv = ford(x); };
+  float med;
+  const bool lin = list != nullptr && sd > 0.f && isfinite(sd) && isfinite(mean);
+  if (!lin || !median_linear(n, m, v1, mean - 4.f * sd, 8.f * sd, sc, work, nwork, &med)) med = median_valid(n, m, k1, sc, list);
+  auto v2 = [&](int i, bool* valid, float* x) { const float y = scale_sign * s[i]; *valid = (lo <= y && y <= hi); *x = fabsf(y - med); };
+  auto k2 = [&](int i, bool* valid, uint32_t* kv) { float x; v2(i, valid, &x); *kv = ford(x); };
+  float mad;
+  if (!lin || !median_linear(n, m, v2, 0.f, 4.f * sd, sc, work, nwork, &mad)) mad = median_valid(n, m, k2, sc, list);
+  return 1.4826f * mad;
 }
 
 // ---- threshold bit-mask + Intersect scans ---------------------------------------------
