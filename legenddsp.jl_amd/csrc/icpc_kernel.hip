@@ -223,35 +223,6 @@ __device__ __forceinline__ float flt_eval_rare(const float* y, const float* c, i
   return flt_eval(y, c, np, f, k);
 }
 
-// The thread's R quads of one trace (S4 view).  FULL (L == 4*NT*R): R back-to-back 16-byte
-// loads with nothing between them; otherwise the address is clamped so that the loads are
-// still unconditional (all in flight together) and out-of-range quads are zeroed afterwards.
-template <int NT, int R, bool FULL>
-__device__ __forceinline__ void load_trace_s4(const float* __restrict__ w, int L, int tid, float (&x)[R][4]) {
-  if (FULL || (L & 3) == 0) {
-    float4 v[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = 4 * (tid + NT * r);
-      v[r] = *reinterpret_cast<const float4*>(w + (FULL ? i : max(min(i, L - 4), 0)));
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const bool ok = FULL || 4 * (tid + NT * r) < L;
-      x[r][0] = ok ? v[r].x : 0.f; x[r][1] = ok ? v[r].y : 0.f; x[r][2] = ok ? v[r].z : 0.f; x[r][3] = ok ? v[r].w : 0.f;
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = 4 * (tid + NT * r);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) x[r][e] = w[min(i + e, L - 1)];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) x[r][e] = (i + e < L) ? x[r][e] : 0.f;
-    }
-  }
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------------------

@@ -119,6 +119,7 @@ int ldsp_ctx_set_option(ldsp_ctx* c, const char* key, int64_t value) {
   if (!c || !key) return fail(LDSP_ERR_INVALID_ARG, "ctx/key is NULL");
   if (!strcmp(key, "cusp_direct")) { c->cusp_direct = value != 0; return LDSP_OK; }
   if (!strcmp(key, "two_kernel")) { c->two_kernel = value != 0; return LDSP_OK; }
+  if (!strcmp(key, "sipm_generic")) { c->sipm_generic = value != 0; return LDSP_OK; }
   if (!strcmp(key, "dbg_stop")) { c->dbg_stop = (int)value; c->icpc_valid = false; return LDSP_OK; }
   return fail(LDSP_ERR_INVALID_ARG, "unknown option '%s'", key);
 }

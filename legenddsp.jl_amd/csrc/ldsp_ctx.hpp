@@ -30,6 +30,7 @@ struct ldsp_ctx {
   int64_t aux_cap = 0;
   float* d_coef = nullptr;  // [LDSP_MAX_FIR_TAPS] staging for functor coefficients / small tables
   int cusp_direct = 0;
+  int sipm_generic = 0; // option "sipm_generic": always the generic two-array dsp_sipm kernel
   int two_kernel = 0;   // option "two_kernel": never fuse the CUSP/ZAC stage into icpc_kernel
   int dbg_stop = 0;
   // timing

@@ -191,6 +191,17 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
   }
 }
 
+#include "sipm_s4.inc"
+
+template <int NT, int R>
+static hipError_t launch_s4(const float* wf, int64_t n, const SipmDev& d, const SipmOutDev& od, hipStream_t st) {
+  const size_t bytes = S4Lds<NT, R>::bytes();
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sipm_s4<NT, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_sipm_s4<NT, R>), dim3((unsigned)n), dim3(NT), bytes, st, wf, d, od);
+  return hipGetLastError();
+}
+
 }  // namespace sipm
 }  // namespace ldsp
 
@@ -229,14 +240,31 @@ extern "C" int ldsp_sipm_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp
   static_assert(sizeof(ldsp_sipm_out) == sizeof(void*) * sipm::S_NCOLS + 4 * sizeof(ldsp_trig_out), "ldsp_sipm_out layout");
   memcpy(od.col, out, sizeof(void*) * sipm::S_NCOLS);
   od.trig[0] = out->trig; od.trig[1] = out->trig_DC; od.trig[2] = out->trig_trap; od.trig[3] = out->trig_DC_trap;
-  const size_t p4 = (size_t)(((L + 3) & ~3) + 64);
-  const size_t bytes = 2 * p4 * 4 + (size_t)(((L + 31) >> 5) + 2) * 4 + 16 + sizeof(tb::Scratch);
-  if (bytes > 160 * 1024) return ldsp_fail(LDSP_ERR_UNSUPPORTED, "dsp_sipm keeps two arrays of the trace in LDS: L <= ~19800 (got %d)", L);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sipm::k_sipm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  const int nt = L <= 4096 ? 256 : (L <= 8192 ? 512 : 1024);
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  hipLaunchKernelGGL(sipm::k_sipm, dim3((unsigned)n), dim3(nt), bytes, c->stream, wf, d, od);
-  hipError_t e = hipGetLastError();
+  // register-resident kernel (one LDS copy of the trace, two traces per CU) when the trace fills a tile and the
+  // filters are the usual short ones; otherwise the generic two-array kernel
+  const bool s4_ok = !c->sipm_generic && p->sg_npts <= sipm::S4_SG_MAX && p->trap.navg <= sipm::S4_LEG_MAX && p->trap.navg2 <= sipm::S4_LEG_MAX;
+  hipError_t e = hipErrorInvalidValue;
+  bool launched = false;
+  if (s4_ok) {
+    launched = true;
+    switch (L) {
+      case 16384: e = sipm::launch_s4<512, 8>(wf, n, d, od, c->stream); break;
+      case 8192: e = sipm::launch_s4<256, 8>(wf, n, d, od, c->stream); break;
+      case 4096: e = sipm::launch_s4<128, 8>(wf, n, d, od, c->stream); break;
+      case 2048: e = sipm::launch_s4<64, 8>(wf, n, d, od, c->stream); break;
+      default: launched = false;
+    }
+  }
+  if (!launched) {
+    const size_t p4 = (size_t)(((L + 3) & ~3) + 64);
+    const size_t bytes = 2 * p4 * 4 + (size_t)(((L + 31) >> 5) + 2) * 4 + 16 + sizeof(tb::Scratch);
+    if (bytes > 160 * 1024) return ldsp_fail(LDSP_ERR_UNSUPPORTED, "dsp_sipm keeps two arrays of the trace in LDS: L <= ~19000 (got %d)", L);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sipm::k_sipm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const int nt = L <= 4096 ? 256 : (L <= 8192 ? 512 : 1024);
+    hipLaunchKernelGGL(sipm::k_sipm, dim3((unsigned)n), dim3(nt), bytes, c->stream, wf, d, od);
+    e = hipGetLastError();
+  }
   if (e != hipSuccess) return ldsp_fail(LDSP_ERR_HIP, "launch: %s", hipGetErrorString(e));
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
   return LDSP_OK;
