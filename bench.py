@@ -9,7 +9,8 @@ over one batch of synthetic HPGe traces that is already resident in HBM.
           kernel and the [n,48] output shards are gathered to rank 0 with one
           RCCL gather inside the timed region (config 4 shape).
 Prints ONE JSON line (rank 0).  `--workload pz_trap` times BASELINE config 2
-(blmean -> shift -> InvCR -> Trap(10us,4us) -> max) instead.
+(blmean -> shift -> InvCR -> Trap(10us,4us) -> max) instead; `--workload sipm` times BASELINE
+config 5's shape (fused dsp_sipm, 16384-sample traces, 625 k per GPU by default).
 """
 import argparse
 import json
@@ -48,14 +49,73 @@ def measured_traffic(kernel, n, L):
     return None
 
 
+def bench_sipm(args, n, L, world, rank, dev):
+    """dsp_sipm (reference src/dsp_sipm.jl:47-158): weak scaling, each rank its own shard; the ragged trigger columns
+    stay on the rank that produced them (fixed-capacity slabs + counts), scalar columns are gathered to rank 0."""
+    params = ldsp.lower_sipm(ldsp.reference_test_sipm_config(), {"sg": {"wl": 200 * ldsp.ns}}, L, 0.0, 16.0)
+    wf = torch.empty((n, L), dtype=torch.float32, device=dev)
+    ldsp.synth.sipm_batch(n, L, device=dev, out=wf)
+    ctx = ldsp.Context(dev.index)
+    ctx.enable_timing(True)
+    bufs = ldsp.sipm_run(wf, params, ctx)      # allocates the output buffers once
+
+    def step():
+        ldsp.sipm_run(wf, params, ctx, out=bufs)
+        if world > 1:
+            ldist.gather_table(bufs[0].t().contiguous(), n * world, dst=0)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kms = []
+    for _ in range(3):
+        ldsp.sipm_run(wf, params, ctx, out=bufs)
+        kms.append(ctx.last_kernel_ms())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        kms = sum(kms) / len(kms)
+        elems = sum(int(bufs[1][g]["count"].clamp(max=ldsp._abi.LDSP_MAX_TRIG).sum()) for g in bufs[1]) * 4   # 4 ragged fields per group
+        bytes_per_trace = 4 * L + 4 * 20 + 8.0 * elems / n      # SURVEY 8(d), C5: measured ragged element count
+        achieved = n * bytes_per_trace / (kms * 1e-3) / 1e9
+        wps = n * world * args.steps / elapsed
+        res = {
+            "metric": "waveforms/s, fused dsp_sipm, 16384-sample f32", "value": wps, "unit": "waveforms/s",
+            "msamples_per_s": wps * L / 1e6, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5 shape: dsp_sipm, 16384-sample f32 traces", "traces_per_gpu": n, "samples": L,
+                       "dt_ns": 16.0, "dsp_config": "reference test/test_dsp_sipm.jl:38-68 + sg.wl = 200 ns",
+                       "ragged_elements_per_trace": elems / n},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_sipm_s4", "kernel_ms": kms, "algorithmic_bytes_per_trace": bytes_per_trace},
+        }
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1_000_000, help="traces per GPU")
-    ap.add_argument("--L", type=int, default=8192)
-    ap.add_argument("--workload", choices=["icpc", "pz_trap"], default="icpc")
+    ap.add_argument("--n", type=int, default=None, help="traces per GPU (default 1 M; 625 k for sipm)")
+    ap.add_argument("--L", type=int, default=None, help="samples per trace (default 8192; 16384 for sipm)")
+    ap.add_argument("--workload", choices=["icpc", "pz_trap", "sipm"], default="icpc")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="traces timed on the host cores (0 = skip); ~10 s on 16 cores")
     args = ap.parse_args()
 
@@ -71,7 +131,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    n, L = args.n, args.L
+    n = args.n if args.n is not None else (625_000 if args.workload == "sipm" else 1_000_000)
+    L = args.L if args.L is not None else (16384 if args.workload == "sipm" else 8192)
+    if args.workload == "sipm":
+        return bench_sipm(args, n, L, world, rank, dev)
     dt = 16.0 * (8192 / L) if L < 8192 else 16.0  # 4096-sample plumbing config needs 32 ns
     cfg = ldsp.reference_test_icpc_config() if L >= 8192 else ldsp.plumbing_icpc_config_4096()
     params = ldsp.lower_icpc(cfg, 500 * ldsp.us, {}, L, 0.0, dt)

@@ -145,9 +145,11 @@ def dsp_icpc(data: Table, config: DSPConfig, tau: float, pars_filter: dict, f_ev
 # ---------------------------------------------------------------------------
 # dsp_sipm
 
-def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None):
+def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None, out=None):
     """Run the fused dsp_sipm kernel (`ldsp_sipm_run`).  Returns (scalars [20, n] float32,
-    {group: {count [n] int32, x/x_high/x_tot/max [n, LDSP_MAX_TRIG] float32}})."""
+    {group: {count [n] int32, x/x_high/x_tot/max [n, LDSP_MAX_TRIG] float32}}).
+    `out`: the pair returned by an earlier call on a batch of the same size — its buffers are reused
+    without re-initialisation (slab entries beyond `count` then keep their old contents)."""
     if not wf.is_cuda:
         raise _lib.LdspError(-103, "sipm_run needs a device-resident waveform tensor (no CPU fallback)")
     ctx = ctx or _lib.default_context(wf.device.index)
@@ -156,18 +158,24 @@ def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None
         raise ValueError(f"waveform length {L} != params.L {params.L}")
     wf = _as_device_f32(wf, wf.device)
     dev = wf.device
-    sc = torch.full((len(_abi.SIPM_SCALAR_COLS), n), float("nan"), dtype=torch.float32, device=dev)
+    cap = _abi.LDSP_MAX_TRIG
+    if out is not None:
+        sc, trig = out
+        if sc.shape != (len(_abi.SIPM_SCALAR_COLS), n) or sc.device != dev:
+            raise ValueError("out= buffers do not match this batch")
+    else:
+        sc = torch.full((len(_abi.SIPM_SCALAR_COLS), n), float("nan"), dtype=torch.float32, device=dev)
+        trig = {}
+        for g in _abi.SIPM_TRIG_GROUPS:
+            cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+            slabs = {k: torch.full((n, cap), float("nan"), dtype=torch.float32, device=dev) for k in ("x", "x_high", "x_tot", "max")}
+            trig[g] = dict(count=cnt, **slabs)
     o = _abi.SipmOut()
     for i, c in enumerate(_abi.SIPM_SCALAR_COLS):
         setattr(o, c, sc[i].data_ptr())
-    trig = {}
-    cap = _abi.LDSP_MAX_TRIG
     for g in _abi.SIPM_TRIG_GROUPS:
-        cnt = torch.zeros(n, dtype=torch.int32, device=dev)
-        slabs = {k: torch.full((n, cap), float("nan"), dtype=torch.float32, device=dev) for k in ("x", "x_high", "x_tot", "max")}
-        setattr(o, g, _abi.TrigOut(cnt.data_ptr(), slabs["x"].data_ptr(), slabs["x_high"].data_ptr(),
-                                   slabs["x_tot"].data_ptr(), slabs["max"].data_ptr()))
-        trig[g] = dict(count=cnt, **slabs)
+        t = trig[g]
+        setattr(o, g, _abi.TrigOut(t["count"].data_ptr(), t["x"].data_ptr(), t["x_high"].data_ptr(), t["x_tot"].data_ptr(), t["max"].data_ptr()))
     ctx.bind_stream()
     _lib.check(_lib.lib().ldsp_sipm_run(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params), C.byref(o)))
     return sc, trig
