@@ -33,9 +33,10 @@ __device__ __forceinline__ Lds carve(unsigned char* raw, int n, bool two) {
   float* after = two ? l.t + pad4(n) : l.t;
   l.bm = reinterpret_cast<uint32_t*>(after);
   const int nw = ((n + 31) >> 5) + 2;
-  uintptr_t p = reinterpret_cast<uintptr_t>(l.bm + nw);
-  p = (p + 15) & ~(uintptr_t)15;
-  l.sc = reinterpret_cast<Scratch*>(p);
+  // offsets as integers, pointers derived from `raw`: a round trip through uintptr_t would turn every access
+  // to the scratch area into a FLAT instruction (the compiler loses the LDS address space)
+  const size_t off = ((size_t)(reinterpret_cast<unsigned char*>(l.bm + nw) - raw) + 15) & ~(size_t)15;
+  l.sc = reinterpret_cast<Scratch*>(raw + off);
   return l;
 }
 static size_t lds_bytes(int n, bool two) {

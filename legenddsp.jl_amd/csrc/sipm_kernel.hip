@@ -54,9 +54,9 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
   float* B = A + pad4(L);
   uint32_t* bm = reinterpret_cast<uint32_t*>(B + pad4(L));
   const int nwmax = ((L + 31) >> 5) + 2;
-  uintptr_t pp = reinterpret_cast<uintptr_t>(bm + nwmax);
-  pp = (pp + 15) & ~(uintptr_t)15;
-  Scratch& sc = *reinterpret_cast<Scratch*>(pp);
+  // (offset arithmetic on integers, pointer derived from `raw`: keeps the LDS address space — see functor_kernels.hip)
+  const size_t sc_off = ((size_t)(reinterpret_cast<unsigned char*>(bm + nwmax) - raw) + 15) & ~(size_t)15;
+  Scratch& sc = *reinterpret_cast<Scratch*>(raw + sc_off);
   const size_t b = blockIdx.x;
   auto put = [&](int c, float v) { if (tid == 0 && out.col[c]) out.col[c][b] = v; };
 
