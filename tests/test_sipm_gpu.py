@@ -75,3 +75,39 @@ def test_sipm_matches_oracle_odd_length(orc):
     sc, trig = ldsp.sipm_run(wf, p)
     ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=8)
     assert _compare(sc, trig, ora, n) <= 1
+
+
+@pytest.mark.parametrize("L,dt", [(4096, 16.0), (8192, 16.0)])
+def test_sipm_register_kernel_other_tiles(orc, L, dt):
+    """The register-resident kernel's other tile sizes (NT = 128, 256) against the oracle."""
+    n = 48
+    p = ldsp.lower_sipm(ldsp.reference_test_sipm_config(), {"sg": {"wl": 200 * ldsp.ns}}, L, 0.0, dt)
+    wf = ldsp.synth.sipm_batch(n, L, device="cuda", seed=21 + L)
+    sc, trig = ldsp.sipm_run(wf, p)
+    ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=8)
+    assert _compare(sc, trig, ora, n) <= 1
+
+
+def test_sipm_quantised_and_degenerate_traces(orc):
+    """Heavily tied values (ADC-like quantisation), a constant trace and an all-out-of-window trace: the medians'
+    refinement / list / radix fall-back paths, in both kernels (register-resident and generic)."""
+    n, L = 24, 16384
+    p = ldsp.lower_sipm(ldsp.reference_test_sipm_config(), {"sg": {"wl": 200 * ldsp.ns}}, L, 0.0, 16.0)
+    wf = ldsp.synth.sipm_batch(n, L, device="cuda", seed=77)
+    wf[:8] = torch.round(wf[:8] * 4) / 4          # steps of 0.25: thousands of equal samples
+    wf[8:12] = torch.round(wf[8:12])              # steps of 1
+    wf[12] = 0.5                                    # constant
+    wf[13] = 100.0 * wf[13]                         # almost everything outside the MAD windows
+    ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=8)
+    ctx = ldsp.default_context()
+    for generic in (0, 1):
+        ctx.set_option("sipm_generic", generic)
+        sc, trig = ldsp.sipm_run(wf, p, ctx)
+        torch.cuda.synchronize()
+        # thresholds are exact order statistics: they must agree tightly whatever path computed them
+        for c in ("threshold", "threshold_DC", "threshold_trap", "threshold_DC_trap"):
+            i = ldsp._abi.SIPM_SCALAR_COLS.index(c)
+            a, b = sc[i].cpu().numpy().astype(np.float64), ora[c]
+            ok = (np.abs(a - b) <= 2e-3 + 1e-4 * np.abs(b)) | (np.isnan(a) & np.isnan(b))
+            assert ok.all(), (generic, c, a[~ok], b[~ok])
+    ctx.set_option("sipm_generic", 0)
