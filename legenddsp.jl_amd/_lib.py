@@ -25,7 +25,7 @@ class LdspError(RuntimeError):
 
 def build(force=False, quiet=True):
     """Compile every HIP source for gfx950 into csrc/libldsp_hip.so (in-tree)."""
-    cmd = ["make", "-C", _CSRC] + (["-B"] if force else []) + (["-s"] if quiet else [])
+    cmd = ["make", "-j4", "-C", _CSRC] + (["-B"] if force else []) + (["-s"] if quiet else [])   # four translation units
     subprocess.check_call(cmd)
     return _SO
 
