@@ -120,3 +120,28 @@ def test_full_size_properties(params):
     for c in ("t10", "t50", "t90", "t99"):
         np.testing.assert_allclose(g2[c], g1[c], atol=2e-3, err_msg=c)
     np.testing.assert_allclose(g2["blmean"], g1["blmean"] + 37.0 + (g1["blmean"] - g1["blmean"]), rtol=1e-5)
+
+
+@pytest.mark.parametrize("Lx", [8000, 8190, 7001])
+def test_trace_lengths_that_do_not_fill_the_tile(orc, Lx):
+    """L < 16*NT (bounds-tested variants of the kernels), a multiple of 4, L % 4 == 2 and odd L (rows not 16-byte aligned)."""
+    p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, Lx, 0.0, 16.0)
+    wf = ldsp.synth.hpge_batch(48, 8192, device="cuda", seed=13)[:, :Lx].contiguous()
+    gpu = _run(wf, p)
+    ora = orc.dsp_icpc(wf.cpu().numpy(), p, nthreads=8)
+    lines, worst = parity.compare(gpu, ora)
+    assert worst <= 0.03, "\n".join(lines)
+
+
+def test_two_launch_form_equals_fused(params):
+    """`two_kernel` = 1 (icpc_kernel + icpc_cz_kernel, the fall-back form) gives the fused launch's table."""
+    wf = ldsp.synth.hpge_batch(96, L, device="cuda", seed=17)
+    fused = _run(wf, params)
+    ctx = ldsp.default_context()
+    ctx.set_option("two_kernel", 1)
+    try:
+        two = _run(wf, params)
+    finally:
+        ctx.set_option("two_kernel", 0)
+    for c in ldsp._abi.ICPC_COLS:
+        np.testing.assert_allclose(two[c], fused[c], rtol=3e-6, atol=1e-3, equal_nan=True, err_msg=c)
