@@ -148,11 +148,13 @@ def main():
     out = torch.empty((n, ncol), dtype=torch.float32, device=dev) if args.workload == "icpc" else \
         torch.empty((2, n), dtype=torch.float32, device=dev)
 
+    gathered = torch.empty((n * world, ncol), dtype=torch.float32, device=dev) if (world > 1 and rank == 0 and args.workload == "icpc") else None
+
     def step():
         if args.workload == "icpc":
             ldsp.icpc_run(wf, params, ctx, out=out)
             if world > 1:
-                ldist.gather_table(out, n * world, dst=0)
+                ldist.gather_table(out, n * world, dst=0, out=gathered)
         else:
             ldsp.icpc_pz_trap_run(wf, params, ctx, out=out)
 

@@ -20,12 +20,14 @@ def shard_range(n: int, world: int, rank: int):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def gather_table(tab: torch.Tensor, n_total: int, dst: int = 0, group=None):
+def gather_table(tab: torch.Tensor, n_total: int, dst: int = 0, group=None, out: torch.Tensor = None):
     """Gather the per-rank [n_r, C] shards into the [n_total, C] table on `dst`
     (row order = global trace index).  Returns the table on dst, None elsewhere.
 
     Shards may differ by one row; they are padded to the largest shard so that a
-    single fixed-size gather moves everything (one collective, direct peer links)."""
+    single fixed-size gather moves everything (one collective, direct peer links).
+    `out` (dst only, optional): a preallocated [world * ceil(n_total / world), C] buffer that receives the
+    shards in place — with equal shards the result is a view of it (no allocation, no copy)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return tab
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -35,10 +37,16 @@ def gather_table(tab: torch.Tensor, n_total: int, dst: int = 0, group=None):
     if tab.shape[0] != nmax:
         send = torch.zeros((nmax, C), dtype=tab.dtype, device=tab.device)
         send[: tab.shape[0]] = tab
-    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, bufs, dst=dst, group=group)
+    bufs = None
+    if rank == dst:
+        if out is None or out.shape != (world * nmax, C) or out.dtype != tab.dtype or out.device != tab.device:
+            out = torch.empty((world * nmax, C), dtype=tab.dtype, device=tab.device)
+        bufs = list(out.split(nmax, dim=0))   # contiguous row blocks of the result: the gather writes the table itself
+    dist.gather(send.contiguous(), bufs, dst=dst, group=group)
     if rank != dst:
         return None
+    if n_total == world * nmax:
+        return out
     parts = []
     for r in range(world):
         lo, hi = shard_range(n_total, world, r)

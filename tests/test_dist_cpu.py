@@ -30,7 +30,14 @@ def _worker(rank, world, port, n, q):
     idx = torch.arange(lo, hi, dtype=torch.float32)
     tab = torch.stack([idx * (c + 1) for c in range(48)], dim=1)
     full = ldist.gather_table(tab, n, dst=0)
+    # second round into a preallocated buffer (what bench.py does every step): equal shards -> the buffer itself
+    nmax = -(-n // world)
+    pre = torch.full((world * nmax, 48), -1.0) if rank == 0 else None
+    again = ldist.gather_table(tab, n, dst=0, out=pre)
     if rank == 0:
+        assert torch.equal(again, full)
+        if n == world * nmax:
+            assert again.data_ptr() == pre.data_ptr()
         q.put(full.numpy())
     else:
         assert full is None
