@@ -145,3 +145,14 @@ def test_two_launch_form_equals_fused(params):
         ctx.set_option("two_kernel", 0)
     for c in ldsp._abi.ICPC_COLS:
         np.testing.assert_allclose(two[c], fused[c], rtol=3e-6, atol=1e-3, equal_nan=True, err_msg=c)
+
+
+def test_long_traces_16384(orc):
+    """L = 16384 (NT = 1024): one trace per CU, the CUSP/ZAC stage runs as the second launch (LDS budget)."""
+    Lx = 16384
+    p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, Lx, 0.0, 16.0)
+    wf = ldsp.synth.hpge_batch(32, Lx, device="cuda", seed=19)
+    gpu = _run(wf, p)
+    ora = orc.dsp_icpc(wf.cpu().numpy(), p, nthreads=8)
+    lines, worst = parity.compare(gpu, ora)
+    assert worst <= 0.04, "\n".join(lines)
