@@ -234,6 +234,28 @@ typedef struct {
 int ldsp_icpc_run(ldsp_ctx* ctx, const float* wf, int64_t n,
                   const ldsp_icpc_params* p, const ldsp_icpc_out* out);
 
+/* ---- "next" row 1: trapezoid filter-optimisation grid scans -----------
+ * dsp_trap_rt_optimization (src/dsp_filter_optimization.jl:102-133: pick-off at a fixed
+ * time, enc_pickoff_trap) and dsp_trap_ft_optimization (:241-274: pick-off at
+ * t50 + rt + ft/2, t50 = first crossing of half the maximum of the pole-zero corrected
+ * trace).  One read of each trace: baseline subtraction (signalstats mean), InvCRFilter,
+ * prefix sum, then for every grid point g the SignalEstimator of the trapezoid output
+ * at the pick-off — G results per trace from G x npts trapezoid samples. */
+#define LDSP_MAX_GRID 64
+typedef struct ldsp_trapgrid_params {
+  int32_t L, _pad0;
+  double t_first, dt;          /* shared time axis of the traces                        */
+  int32_t bl_from, bl_until;   /* signalstats window (0-based samples, inclusive)       */
+  double pz_c;                 /* dt / tau of the InvCRFilter                           */
+  ldsp_dni sig_est;            /* SignalEstimator(PolynomialDNI(degree, npts))          */
+  int32_t pick_mode;           /* 0: pick-off at `pick_time`; 1: at t50 + offsets[g]    */
+  int32_t tx_mintot;           /* Intersect(mintot) in samples (mode 1)                 */
+  double pick_time;            /* mode 0, time-axis units                               */
+} ldsp_trapgrid_params;
+/* traps[G] in samples; offsets[G] (time-axis units, mode 1; may be NULL in mode 0); out [G][n] float (device). */
+int ldsp_trap_grid_run(ldsp_ctx* ctx, const float* wf, int64_t n, const ldsp_trapgrid_params* p, int32_t G,
+                       const ldsp_trap* traps, const double* offsets, float* out);
+
 /* BASELINE config 2: the e_10410 column path only — signalstats(bl) -> shift
  * -> InvCRFilter -> TrapezoidalChargeFilter(10us,4us) -> maximum
  * (src/dsp_icpc.jl:102-105,119-120,147-148).  Writes blmean[n], e_10410[n]. */

@@ -17,6 +17,7 @@ from .filters import (SamplingInfo, smplinfo, fltinstance, rdfilt_, flt_output_l
                       flt_output_time_axis, InvCRFilter, IntegratorFilter, TrapezoidalChargeFilter, CUSPChargeFilter,
                       ZACChargeFilter, SavitzkyGolayFilter, DerivativeFilter, HaarAveragingFilter, MovingWindowFilter,
                       MovingWindowMultiFilter, TruncateFilter, shift_waveform, multiply_waveform, reverse_waveform)
+from .optimization import dsp_trap_rt_optimization, dsp_trap_ft_optimization, trap_grid_run, lower_trap_grid
 from .extractors import (VectorOfVectors, signalstats, tailstats, extremestats, thresholdstats, thresholdstats_mad,
                          saturation, get_wvf_maximum, Intersect, IntersectMaximum, MultiIntersect, PolynomialDNI,
                          SignalEstimator)

@@ -123,3 +123,13 @@ SIPM_TRIG_GROUPS = ["trig", "trig_DC", "trig_trap", "trig_DC_trap"]
 
 class SipmOut(C.Structure):
     _fields_ = [(c, C.c_void_p) for c in SIPM_SCALAR_COLS] + [(g, TrigOut) for g in SIPM_TRIG_GROUPS]
+
+
+LDSP_MAX_GRID = 64
+
+
+class TrapGridParams(C.Structure):
+    """ldsp_trapgrid_params (include/ldsp.h)."""
+    _fields_ = [("L", C.c_int32), ("_pad0", C.c_int32), ("t_first", C.c_double), ("dt", C.c_double),
+                ("bl_from", C.c_int32), ("bl_until", C.c_int32), ("pz_c", C.c_double), ("sig_est", Dni),
+                ("pick_mode", C.c_int32), ("tx_mintot", C.c_int32), ("pick_time", C.c_double)]

@@ -70,6 +70,12 @@ class StepRange:
         n = math.floor((self.stop - self.start) / self.step + 1e-9)
         return self.start + n * self.step
 
+    def __len__(self):
+        return int(math.floor((self.stop - self.start) / self.step + 1e-9)) + 1
+
+    def __iter__(self):   # the grid scans (dsp_filter_optimization.jl) enumerate the range
+        return (self.start + i * self.step for i in range(len(self)))
+
 
 def _interval(x) -> ClosedInterval:
     if isinstance(x, ClosedInterval):

@@ -53,6 +53,20 @@ struct CuspZacDev {
   float zu_coef[12];
 };
 
+// trapezoid grid scan (ldsp_trap_grid_run): one parameter block in device memory
+struct TrapGridDev {
+  int32_t L, NT, G, pick_mode, tx_mintot;
+  float t_first, dt;
+  WinDev bl;
+  float pz_c;
+  double pz_c64;
+  EstDev est;
+  int32_t pick_ip;   // mode 0: pick-off position in samples, split int + frac
+  float pick_fp;
+  TrapDev trap[64];
+  float offs[64];    // mode 1: offsets in samples
+};
+
 struct IcpcDev {
   int32_t L, NT, R;   // trace length; threads and float4 rows per thread of the launch
   float t_first, dt, unit_per_us, inv_unit_per_us;

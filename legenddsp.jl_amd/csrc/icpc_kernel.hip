@@ -1423,6 +1423,140 @@ pz_trap_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, flo
   }
 }
 
+// ---------------------------------------------------------------------------
+// Trapezoid filter-optimisation grid scans (reference src/dsp_filter_optimization.jl:102-133 and
+// :241-274): baseline mean -> shift -> InvCR -> T = prefix sum (as pz_trap_kernel), then for every
+// grid point g the SignalEstimator of TrapezoidalChargeFilter_g's output at the pick-off, i.e.
+// npts trapezoid samples (4 reads of T each) per grid point instead of a filtered trace.  One wave
+// per grid point, round robin.  pick_mode 1 needs t50 first: half the maximum of y, Intersect.
+template <int NT, int R, bool FULL>
+__global__ void __launch_bounds__(NT)
+trap_grid_kernel(const float* __restrict__ wf, const TrapGridDev* __restrict__ Pp, float* __restrict__ out, int64_t n) {
+  constexpr int NW = NT / 64, SP = 4 * R, Lp = NT * SP, NWORDS = Lp / 32;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const TrapGridDev& P = *Pp;
+  const int L = FULL ? Lp : P.L, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  float* T = reinterpret_cast<float*>(smem_raw);                                   // [Lp+64]
+  float* Y = T + Lp + 64;                                                           // [Lp]
+  uint32_t* bm = reinterpret_cast<uint32_t*>(Y + Lp);                               // [NWORDS]
+  double* part = reinterpret_cast<double*>(smem_raw + (size_t)(2 * Lp + 64 + NWORDS) * 4);   // [2][R*NW]
+  double* wsum = part + 2 * R * NW;                                                 // [NW]
+  float* estB = reinterpret_cast<float*>(wsum + NW);                                // [EST_TBL]
+  uint32_t* slot = reinterpret_cast<uint32_t*>(estB + EST_TBL);                     // [4] max(y), first crossing, count
+  const float* w = wf + (size_t)blockIdx.x * (size_t)L;
+  float x[R][4];
+  load_trace_s4<NT, R, FULL>(w, L, tid, x);
+  for (int i = tid; i < EST_TBL; i += NT) estB[i] = P.est.B[i];
+  if (tid < 64) T[Lp + tid] = 0.f;
+  if (tid == 0) { slot[0] = 0u; slot[1] = 0x7fffffffu; slot[2] = 0u; }
+  // baseline mean exactly as icpc_kernel forms it
+  const float pv_bl = w[P.bl.from];
+  WinAccF bl = {0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < R; ++r) winf_accum4(bl, P.bl, 4 * (tid + NT * r), 0.f, pv_bl, x[r][0], x[r][1], x[r][2], x[r][3]);
+  const float s1w = wave_incl_scan_sum(bl.s1);
+  if (lane == 63) wsum[wave] = (double)s1w;
+  __syncthreads();
+  double s1 = 0;
+  for (int ww = 0; ww < NW; ++ww) s1 += wsum[ww];
+  const float blmean = (float)((double)pv_bl + s1 * P.bl.inv_n);
+  float tot[R];
+  double off[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i0 = 4 * (tid + NT * r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[r][e] = (i0 + e < L) ? x[r][e] - blmean : 0.f;
+    tot[r] = (x[r][0] + x[r][1]) + (x[r][2] + x[r][3]);
+  }
+  s4_exscan_sum<NT, R>(tot, off, part, nullptr);
+  float ymax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i0 = 4 * (tid + NT * r);
+    const float coff = (float)(P.pz_c64 * off[r]);
+    float run = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      run += x[r][e];
+      x[r][e] = (i0 + e < L) ? (x[r][e] + coff) + P.pz_c * run : 0.f;
+      ymax = vmax(ymax, (i0 + e < L) ? x[r][e] : -INFINITY);
+    }
+    tot[r] = (x[r][0] + x[r][1]) + (x[r][2] + x[r][3]);
+    *reinterpret_cast<float4*>(&Y[i0]) = make_float4(x[r][0], x[r][1], x[r][2], x[r][3]);
+  }
+  ymax = wave_max_all(ymax);
+  if (lane == 0) atomicMax(&slot[0], ford(ymax));
+  double tot_all;
+  s4_exscan_sum<NT, R>(tot, off, part + R * NW, &tot_all);   // barrier inside: Y and the maximum are published
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double run = off[r];
+    float4 t;
+    float* pt = &t.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pt[e] = (float)run; run += (double)x[r][e]; }
+    *reinterpret_cast<float4*>(&T[4 * (tid + NT * r)]) = t;
+  }
+  if (tid == 0) T[Lp] = (float)tot_all;
+  // pick-off position (samples, int + frac)
+  Pos base;
+  base.ip = P.pick_ip; base.fp = P.pick_fp;
+  if (P.pick_mode == 1) {  // t50 = get_threshold(wvfs, 0.5 * maximum; mintot)   dsp_filter_optimization.jl:260
+    const float thr = 0.5f * ford_inv(slot[0]);
+#pragma unroll
+    for (int m = 0; m < SP; ++m) {
+      const int k = tid + NT * m;
+      const unsigned long long bq = __ballot(k < L && Y[k] >= thr);
+      if (lane == 0) *reinterpret_cast<unsigned long long*>(&bm[(NT >> 5) * m + 2 * wave]) = bq;
+    }
+    __syncthreads();
+    for (int wd = tid; wd < NWORDS; wd += NT) {
+      int c, f;
+      intersect_word(bm, wd, NWORDS, P.tx_mintot, &c, &f);
+      if (c) { atomicAdd(&slot[2], (uint32_t)c); atomicMin(reinterpret_cast<int*>(&slot[1]), f); }
+    }
+    __syncthreads();
+    if (slot[2] > 0) {
+      const int p = (int)slot[1];
+      const float yl = Y[p - 1], yh = Y[p];
+      base.ip = p - 1; base.fp = (thr - yl) / (yh - yl);
+    } else {               // no crossing: NaN -> 0 us (dsp_routines.jl:41), i.e. the position of t = 0
+      base.ip = 0; base.fp = -P.t_first / P.dt;
+      base = pos_norm(base);
+    }
+  } else {
+    __syncthreads();
+  }
+  for (int g = wave; g < P.G; g += NW) {
+    const TrapDev tr = P.trap[g];
+    Pos p = (P.pick_mode == 1) ? pos_add(base, P.offs[g]) : base;
+    p.ip -= (tr.flen - 1);   // trailing alignment of the filter output (A1)
+    const float v = estimate(P.est, estB, p, L - tr.flen + 1, [&](int i) { return trap_at(T, i, tr); });
+    if (lane == 0) out[(size_t)g * (size_t)n + blockIdx.x] = v;
+  }
+}
+
+template <int NT, int R, bool FULL>
+static hipError_t launch_grid_t(const float* wf, int64_t n, const TrapGridDev* dP, float* out, hipStream_t st) {
+  constexpr int NW = NT / 64, Lp = 16 * NT;
+  const size_t smem = (size_t)(2 * Lp + 64 + Lp / 32) * 4 + (2 * R * NW + NW) * 8 + EST_TBL * 4 + 32;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trap_grid_kernel<NT, R, FULL>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((trap_grid_kernel<NT, R, FULL>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, out, n);
+  return hipGetLastError();
+}
+hipError_t launch_trap_grid(const float* wf, int64_t n, int NT, bool full, const TrapGridDev* dP, float* out, hipStream_t st) {
+#define LDSP_CASE(N) \
+  case N: return full ? launch_grid_t<N, 4, true>(wf, n, dP, out, st) : launch_grid_t<N, 4, false>(wf, n, dP, out, st);
+  switch (NT) {
+    LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
+    default: return hipErrorInvalidValue;
+  }
+#undef LDSP_CASE
+}
+
 // Largest dynamic LDS size that still lets two workgroups share a CU (160 KiB, 1280-byte granules)
 constexpr size_t LDS_TWO_PER_CU = 80640;
 

@@ -1,0 +1,72 @@
+"""Filter-optimisation grid scans (reference src/dsp_filter_optimization.jl) — SURVEY 8(f) row 1, trapezoid part.
+
+`dsp_trap_rt_optimization(wvfs, config, tau; ft)` (:102-133) and `dsp_trap_ft_optimization(wvfs, config, tau, rt)`
+(:241-274): baseline subtraction, pole-zero deconvolution, then for every grid value the `SignalEstimator` of the
+trapezoid-filtered trace at a pick-off.  Here one kernel launch (`ldsp_trap_grid_run`) reads each trace once and
+returns the dense `[grid, n]` float32 matrix (the reference: Float64 / Float32 matrices of the same shape).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi, _lib
+from .config import DSPConfig, WindowError, nsamples, trap_samples, window_index
+from .routines import ArrayOfRDWaveforms, _as_device_f32
+
+
+def lower_trap_grid(config: DSPConfig, tau: float, L: int, t_first: float, dt: float, pick_mode: int, pick_time: float = 0.0):
+    kw = config.kwargs_pars
+    p = _abi.TrapGridParams()
+    p.L, p.t_first, p.dt = int(L), float(t_first), float(dt)
+    p.bl_from = window_index(config.bl_window.left, t_first, dt)
+    p.bl_until = window_index(config.bl_window.right, t_first, dt)
+    if not (0 <= p.bl_from <= p.bl_until <= L - 1):
+        raise WindowError(f"bl_window [{p.bl_from},{p.bl_until}] outside a trace of {L} samples")
+    p.pz_c = float(dt) / float(tau)
+    p.sig_est = _abi.Dni(nsamples(kw.sig_interpolation_length, dt), int(kw.sig_interpolation_order))
+    p.pick_mode, p.tx_mintot, p.pick_time = int(pick_mode), max(1, nsamples(kw.tx_mintot, dt)), float(pick_time)
+    return p
+
+
+def trap_grid_run(wf: torch.Tensor, params: _abi.TrapGridParams, traps, offsets=None, ctx: _lib.Context = None) -> torch.Tensor:
+    """`ldsp_trap_grid_run`: [G, n] float32 device tensor."""
+    if not wf.is_cuda:
+        raise _lib.LdspError(-103, "trap_grid_run needs a device-resident waveform tensor (no CPU fallback)")
+    ctx = ctx or _lib.default_context(wf.device.index)
+    n, L = wf.shape
+    if L != params.L:
+        raise ValueError(f"waveform length {L} != params.L {params.L}")
+    wf = _as_device_f32(wf, wf.device)
+    G = len(traps)
+    tr = (_abi.Trap * G)(*traps)
+    offs = None
+    if offsets is not None:
+        offs = np.ascontiguousarray(offsets, dtype=np.float64)
+        assert len(offs) == G
+    out = torch.empty((G, n), dtype=torch.float32, device=wf.device)
+    ctx.bind_stream()
+    _lib.check(_lib.lib().ldsp_trap_grid_run(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params), G, C.cast(tr, C.c_void_p),
+                                             offs.ctypes.data_as(C.c_void_p) if offs is not None else None, C.c_void_p(out.data_ptr())))
+    return out
+
+
+def dsp_trap_rt_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, ft: float = 2000.0, ctx=None) -> torch.Tensor:
+    """ENC grid over the trapezoid rise times `config.e_grid_rt_trap` at flat-top `ft` (ns); pick-off at
+    `config.enc_pickoff_trap` (reference :102-133).  Returns `[len(grid), n]`."""
+    grid = list(config.e_grid_rt_trap)
+    p = lower_trap_grid(config, tau, wvfs.nsamples, wvfs.t_first, wvfs.dt, 0, config.enc_pickoff_trap)
+    traps = [trap_samples(rt, ft, wvfs.dt) for rt in grid]
+    return trap_grid_run(wvfs.signal, p, traps, None, ctx)
+
+
+def dsp_trap_ft_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, rt: float, ctx=None) -> torch.Tensor:
+    """Energy grid over the flat-top times `config.e_grid_ft_trap` at rise time `rt` (ns); pick-off at
+    t50 + rt + ft/2 (reference :241-274).  Returns `[len(grid), n]`."""
+    grid = list(config.e_grid_ft_trap)
+    p = lower_trap_grid(config, tau, wvfs.nsamples, wvfs.t_first, wvfs.dt, 1)
+    traps = [trap_samples(rt, ft, wvfs.dt) for ft in grid]
+    offsets = [float(rt) + float(ft) / 2 for ft in grid]
+    return trap_grid_run(wvfs.signal, p, traps, offsets, ctx)

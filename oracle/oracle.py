@@ -229,3 +229,26 @@ def dsp_sipm(wf, params: _abi.SipmParams, cap=_abi.LDSP_MAX_TRIG, nthreads=1):
         res[name] = dict(count=cnt[:, g].copy(), x=tr[:, 4 * g + 0], x_high=tr[:, 4 * g + 1],
                          x_tot=tr[:, 4 * g + 2], max=tr[:, 4 * g + 3])
     return res
+
+
+def trap_grid(wf, params, traps, offsets=None):
+    """CPU restatement of ldsp_trap_grid_run (reference src/dsp_filter_optimization.jl:102-133, :241-274), composed
+    from the functor restatements above, trace by trace: signalstats mean -> shift -> InvCR -> [t50] ->
+    per grid point TrapezoidalChargeFilter -> SignalEstimator at the pick-off.  Returns [G, n] float64."""
+    wf = np.asarray(wf, dtype=np.float64)
+    n, L = wf.shape
+    t0, dt = params.t_first, params.dt
+    out = np.empty((len(traps), n))
+    for i in range(n):
+        x = wf[i] - signalstats(wf[i], params.bl_from, params.bl_until, t0, dt)["mean"]
+        y = invcr(x, params.pz_c)
+        if params.pick_mode == 1:
+            r = intersect(y, 0.5 * y.max(), params.tx_mintot, t0, dt)
+            t50 = 0.0 if np.isnan(r["x"]) else r["x"]      # get_threshold: NaN -> 0 (dsp_routines.jl:41)
+        for g, tr in enumerate(traps):
+            f = trap(y, tr.navg, tr.ngap, tr.navg2)
+            flen = tr.navg + tr.ngap + tr.navg2
+            tf = t0 + dt * (flen - 1)                        # trailing alignment (A1)
+            t = params.pick_time if params.pick_mode == 0 else t50 + offsets[g]
+            out[g, i] = signal_estimator(f, t, params.sig_est.npts, params.sig_est.degree, tf, dt)
+    return out

@@ -1,0 +1,51 @@
+"""SURVEY 8(f) row 1, trapezoid part: the filter-optimisation grid scans against the oracle (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+import legenddsp_jl_amd as ldsp
+
+pytestmark = pytest.mark.gpu
+L = 8192
+
+
+def _oracle(orc, wvfs, p, traps, offsets):
+    return orc.trap_grid(wvfs.signal.cpu().numpy(), p, traps, offsets)
+
+
+def test_trap_rt_optimization_matches_oracle(orc):
+    cfg = ldsp.reference_test_icpc_config()
+    wvfs = ldsp.ArrayOfRDWaveforms(ldsp.synth.hpge_batch(48, L, device="cuda", seed=31), 0.0, 16.0)
+    grid = list(cfg.e_grid_rt_trap)
+    out = ldsp.dsp_trap_rt_optimization(wvfs, cfg, 500 * ldsp.us, ft=2 * ldsp.us).cpu().numpy()
+    assert out.shape == (len(grid), 48)
+    p = ldsp.lower_trap_grid(cfg, 500 * ldsp.us, L, 0.0, 16.0, 0, cfg.enc_pickoff_trap)
+    traps = [ldsp.config.trap_samples(rt, 2 * ldsp.us, 16.0) for rt in grid]
+    ora = _oracle(orc, wvfs, p, traps, None)
+    # the pick-off sits on the baseline side of the pulse for most grid values (ENC scan): values of a few ADC
+    np.testing.assert_allclose(out, ora, rtol=2e-5, atol=0.05)
+
+
+def test_trap_ft_optimization_matches_oracle(orc):
+    cfg = ldsp.reference_test_icpc_config()
+    wvfs = ldsp.ArrayOfRDWaveforms(ldsp.synth.hpge_batch(48, L, device="cuda", seed=32), 0.0, 16.0)
+    rt = 8 * ldsp.us
+    grid = list(cfg.e_grid_ft_trap)
+    out = ldsp.dsp_trap_ft_optimization(wvfs, cfg, 500 * ldsp.us, rt).cpu().numpy()
+    p = ldsp.lower_trap_grid(cfg, 500 * ldsp.us, L, 0.0, 16.0, 1)
+    traps = [ldsp.config.trap_samples(rt, ft, 16.0) for ft in grid]
+    offsets = [rt + ft / 2 for ft in grid]
+    ora = _oracle(orc, wvfs, p, traps, offsets)
+    np.testing.assert_allclose(out, ora, rtol=2e-5, atol=0.05)
+    # energies on the flat top: close to the full chain's e_trap scale (amplitude of the pulses)
+    assert np.all(out > 100.0)
+
+
+def test_grid_argument_checks():
+    cfg = ldsp.reference_test_icpc_config()
+    wvfs = ldsp.ArrayOfRDWaveforms(ldsp.synth.hpge_batch(4, L, device="cuda"), 0.0, 16.0)
+    p = ldsp.lower_trap_grid(cfg, 500 * ldsp.us, L, 0.0, 16.0, 0, cfg.enc_pickoff_trap)
+    with pytest.raises(ldsp.LdspError):   # trapezoid longer than the trace
+        ldsp.trap_grid_run(wvfs.signal, p, [ldsp._abi.Trap(5000, 10, 5000)])
+    with pytest.raises(ldsp.LdspError):   # more grid points than the kernel holds
+        ldsp.trap_grid_run(wvfs.signal, p, [ldsp._abi.Trap(10, 2, 10)] * (ldsp._abi.LDSP_MAX_GRID + 1))
