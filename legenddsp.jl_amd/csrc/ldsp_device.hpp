@@ -169,6 +169,7 @@ __device__ __forceinline__ bool bits_all_set(const uint32_t* bm, int s, int len,
 // not start at sample 0 and are at least min_n long; *first = start of the first one.
 __device__ __forceinline__ void intersect_word(const uint32_t* bm, int w, int nwords, int min_n, int* cnt, int* first) {
   uint32_t h = bm[w];
+  if (h == 0u) { *cnt = 0; *first = 0x7fffffff; return; }  // no run can start in an empty word (most words of a sparse mask)
   uint32_t prev = (w == 0) ? 1u : (bm[w - 1] >> 31);  // sample -1 counts as "high": initial run excluded
   uint32_t starts = h & ~((h << 1) | prev);
   if (min_n >= 2) {  // cheap prune: the sample after a run start must be high too
@@ -188,6 +189,7 @@ __device__ __forceinline__ void intersect_word(const uint32_t* bm, int w, int nw
 // runs that do not touch the last sample n-1, at least min_n long; *last_end = largest end index.
 __device__ __forceinline__ void intersect_word_rev(const uint32_t* bm, int w, int nwords, int n, int min_n, int* cnt, int* last_end) {
   uint32_t h = bm[w];
+  if (h == 0u) { *cnt = 0; *last_end = -1; return; }
   uint32_t nextbit;
   if (32 * w + 32 == n) nextbit = 1u;  // the sample just past the end counts as "high"
   else nextbit = (w + 1 < nwords) ? (bm[w + 1] & 1u) : 0u;
