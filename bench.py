@@ -251,8 +251,14 @@ def main():
             t1 = time.perf_counter()
             orc.dsp_icpc(host, params, nthreads=cores)
             cpu_t = time.perf_counter() - t1
+            # the reference itself is single-threaded: the same restatement on one core, smaller sample
+            m1 = min(2048, m)
+            t2 = time.perf_counter()
+            orc.dsp_icpc(host[:m1], params, nthreads=1)
+            cpu_t1 = time.perf_counter() - t2
             res["cpu_baseline"] = {
                 "value": m / cpu_t, "unit": "waveforms/s", "cores": cores, "kind": "port",
+                "single_thread": {"value": m1 / cpu_t1, "unit": "waveforms/s", "cores": 1, "sample": f"first {m1} traces"},
                 "sample": f"first {m} traces of the same batch, float64 CPU restatement (oracle/ldsp_oracle.c), "
                           f"OpenMP over traces, direct-form CUSP/ZAC; proxy for the single-threaded Julia reference",
             }
