@@ -222,8 +222,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE config 3: 1M x 8192 f32, full dsp_icpc chain" if args.workload == "icpc"
-                                    else "BASELINE config 2: 1M x 8192 f32, pole-zero + trapezoid"),
+            "config": {"workload": (f"BASELINE config 3: {n} x {L} f32, full dsp_icpc chain" if args.workload == "icpc"
+                                    else f"BASELINE config 2: {n} x {L} f32, pole-zero + trapezoid"),
                        "traces_per_gpu": n, "samples": L, "dt_ns": dt,
                        "dsp_config": "reference test/test_dsp_icpc.jl:50-161", "tau_us": 500,
                        "gather": "rccl gather of [n,48] f32 to rank 0" if world > 1 else "none"},
