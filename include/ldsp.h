@@ -256,6 +256,14 @@ typedef struct ldsp_trapgrid_params {
 int ldsp_trap_grid_run(ldsp_ctx* ctx, const float* wf, int64_t n, const ldsp_trapgrid_params* p, int32_t G,
                        const ldsp_trap* traps, const double* offsets, float* out);
 
+/* The same scan for an arbitrary FIR filter per grid point — dsp_cusp_rt_optimization / dsp_zac_rt_optimization
+ * (src/dsp_filter_optimization.jl:145-181, 193-229) and the *_ft_optimization pair (:286-324, 336-374): taps[g] =
+ * the Lf coefficients of grid point g (HOST pointer, [G][Lf] doubles, e.g. from ldsp_cusp_coeffs / ldsp_zac_coeffs;
+ * valid-mode, trailing time axis, as ldsp_rdfilt_fir).  Only the npts outputs under the SignalEstimator window are
+ * evaluated (direct form, npts x Lf multiply-adds per grid point and trace).  p: as for ldsp_trap_grid_run. */
+int ldsp_fir_grid_run(ldsp_ctx* ctx, const float* wf, int64_t n, const ldsp_trapgrid_params* p, int32_t G, int32_t Lf,
+                      const double* taps, const double* offsets, float* out);
+
 /* BASELINE config 2: the e_10410 column path only — signalstats(bl) -> shift
  * -> InvCRFilter -> TrapezoidalChargeFilter(10us,4us) -> maximum
  * (src/dsp_icpc.jl:102-105,119-120,147-148).  Writes blmean[n], e_10410[n]. */

@@ -67,6 +67,20 @@ struct TrapGridDev {
   float offs[64];    // mode 1: offsets in samples
 };
 
+// FIR grid scan (ldsp_fir_grid_run)
+struct FirGridDev {
+  int32_t L, NT, G, Lf, pick_mode, tx_mintot;
+  float t_first, dt;
+  WinDev bl;
+  float pz_c;
+  double pz_c64;
+  EstDev est;
+  int32_t pick_ip;
+  float pick_fp;
+  float offs[64];
+  const float* taps;   // device, [G][Lf], taps REVERSED (correlation form: out[k] = sum_j c[j] y[k+j])
+};
+
 struct IcpcDev {
   int32_t L, NT, R;   // trace length; threads and float4 rows per thread of the launch
   float t_first, dt, unit_per_us, inv_unit_per_us;

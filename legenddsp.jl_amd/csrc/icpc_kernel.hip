@@ -1557,6 +1557,133 @@ hipError_t launch_trap_grid(const float* wf, int64_t n, int NT, bool full, const
 #undef LDSP_CASE
 }
 
+// ---------------------------------------------------------------------------
+// FIR filter-optimisation grid scans (CUSP / ZAC: reference src/dsp_filter_optimization.jl:145-229, 286-374).
+// Front end as trap_grid_kernel (y only: no prefix sum); per grid point one wave evaluates, in direct form,
+// just the npts filter outputs under the SignalEstimator window: lane l <-> output i0+l, consecutive lanes on
+// consecutive LDS words, one scalar tap load per 16 taps.
+template <int NT, int R, bool FULL>
+__global__ void __launch_bounds__(NT)
+fir_grid_kernel(const float* __restrict__ wf, const FirGridDev* __restrict__ Pp, float* __restrict__ out, int64_t n) {
+  constexpr int NW = NT / 64, SP = 4 * R, Lp = NT * SP, NWORDS = Lp / 32;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const FirGridDev& P = *Pp;
+  const int L = FULL ? Lp : P.L, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  float* Y = reinterpret_cast<float*>(smem_raw);                                    // [Lp+64]
+  uint32_t* bm = reinterpret_cast<uint32_t*>(Y + Lp + 64);                          // [NWORDS]
+  double* part = reinterpret_cast<double*>(smem_raw + (size_t)(Lp + 64 + NWORDS) * 4);   // [R*NW]
+  double* wsum = part + R * NW;                                                     // [NW]
+  float* estB = reinterpret_cast<float*>(wsum + NW);                                // [EST_TBL]
+  uint32_t* slot = reinterpret_cast<uint32_t*>(estB + EST_TBL);                     // [4]
+  const float* w = wf + (size_t)blockIdx.x * (size_t)L;
+  float x[R][4];
+  load_trace_s4<NT, R, FULL>(w, L, tid, x);
+  for (int i = tid; i < EST_TBL; i += NT) estB[i] = P.est.B[i];
+  if (tid < 64) Y[Lp + tid] = 0.f;
+  if (tid == 0) { slot[0] = 0u; slot[1] = 0x7fffffffu; slot[2] = 0u; }
+  const float pv_bl = w[P.bl.from];
+  WinAccF bl = {0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < R; ++r) winf_accum4(bl, P.bl, 4 * (tid + NT * r), 0.f, pv_bl, x[r][0], x[r][1], x[r][2], x[r][3]);
+  const float s1w = wave_incl_scan_sum(bl.s1);
+  if (lane == 63) wsum[wave] = (double)s1w;
+  __syncthreads();
+  double s1 = 0;
+  for (int ww = 0; ww < NW; ++ww) s1 += wsum[ww];
+  const float blmean = (float)((double)pv_bl + s1 * P.bl.inv_n);
+  float tot[R];
+  double off[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i0 = 4 * (tid + NT * r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[r][e] = (i0 + e < L) ? x[r][e] - blmean : 0.f;
+    tot[r] = (x[r][0] + x[r][1]) + (x[r][2] + x[r][3]);
+  }
+  s4_exscan_sum<NT, R>(tot, off, part, nullptr);
+  float ymax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i0 = 4 * (tid + NT * r);
+    const float coff = (float)(P.pz_c64 * off[r]);
+    float run = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      run += x[r][e];
+      x[r][e] = (i0 + e < L) ? (x[r][e] + coff) + P.pz_c * run : 0.f;
+      ymax = vmax(ymax, (i0 + e < L) ? x[r][e] : -INFINITY);
+    }
+    *reinterpret_cast<float4*>(&Y[i0]) = make_float4(x[r][0], x[r][1], x[r][2], x[r][3]);
+  }
+  ymax = wave_max_all(ymax);
+  if (lane == 0) atomicMax(&slot[0], ford(ymax));
+  __syncthreads();
+  Pos base;
+  base.ip = P.pick_ip; base.fp = P.pick_fp;
+  if (P.pick_mode == 1) {  // t50 = get_threshold(wvfs, 0.5 * maximum; mintot)
+    const float thr = 0.5f * ford_inv(slot[0]);
+#pragma unroll
+    for (int m = 0; m < SP; ++m) {
+      const int k = tid + NT * m;
+      const unsigned long long bq = __ballot(k < L && Y[k] >= thr);
+      if (lane == 0) *reinterpret_cast<unsigned long long*>(&bm[(NT >> 5) * m + 2 * wave]) = bq;
+    }
+    __syncthreads();
+    for (int wd = tid; wd < NWORDS; wd += NT) {
+      int c, f;
+      intersect_word(bm, wd, NWORDS, P.tx_mintot, &c, &f);
+      if (c) { atomicAdd(&slot[2], (uint32_t)c); atomicMin(reinterpret_cast<int*>(&slot[1]), f); }
+    }
+    __syncthreads();
+    if (slot[2] > 0) {
+      const int p = (int)slot[1];
+      const float yl = Y[p - 1], yh = Y[p];
+      base.ip = p - 1; base.fp = (thr - yl) / (yh - yl);
+    } else {
+      base.ip = 0; base.fp = -P.t_first / P.dt;
+      base = pos_norm(base);
+    }
+  }
+  const int Lf = P.Lf, nout = L - Lf + 1;
+  for (int g = wave; g < P.G; g += NW) {
+    const float* c = P.taps + (size_t)g * (size_t)Lf;   // wave-uniform pointer: the tap reads are scalar loads
+    Pos p = (P.pick_mode == 1) ? pos_add(base, P.offs[g]) : base;
+    p.ip -= (Lf - 1);   // trailing alignment of the filter output (A1)
+    const float v = estimate(P.est, estB, p, nout, [&](int i) {
+      const float* yp = &Y[i];
+      float a0 = 0.f, a1 = 0.f;
+      int j = 0;
+      for (; j + 16 <= Lf; j += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) { a0 = fmaf(c[j + u], yp[j + u], a0); a1 = fmaf(c[j + u + 1], yp[j + u + 1], a1); }
+      }
+      for (; j < Lf; ++j) a0 = fmaf(c[j], yp[j], a0);
+      return a0 + a1;
+    });
+    if (lane == 0) out[(size_t)g * (size_t)n + blockIdx.x] = v;
+  }
+}
+
+template <int NT, int R, bool FULL>
+static hipError_t launch_fir_grid_t(const float* wf, int64_t n, const FirGridDev* dP, float* out, hipStream_t st) {
+  constexpr int NW = NT / 64, Lp = 16 * NT;
+  const size_t smem = (size_t)(Lp + 64 + Lp / 32) * 4 + (R * NW + NW) * 8 + EST_TBL * 4 + 32;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_grid_kernel<NT, R, FULL>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((fir_grid_kernel<NT, R, FULL>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, out, n);
+  return hipGetLastError();
+}
+hipError_t launch_fir_grid(const float* wf, int64_t n, int NT, bool full, const FirGridDev* dP, float* out, hipStream_t st) {
+#define LDSP_CASE(N) \
+  case N: return full ? launch_fir_grid_t<N, 4, true>(wf, n, dP, out, st) : launch_fir_grid_t<N, 4, false>(wf, n, dP, out, st);
+  switch (NT) {
+    LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
+    default: return hipErrorInvalidValue;
+  }
+#undef LDSP_CASE
+}
+
 // Largest dynamic LDS size that still lets two workgroups share a CU (160 KiB, 1280-byte granules)
 constexpr size_t LDS_TWO_PER_CU = 80640;
 

@@ -22,6 +22,7 @@ hipError_t launch_icpc(const float* wf, int64_t n, int NT, bool full, const Icpc
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 size_t icpc_smem_bytes(int NT);
 hipError_t launch_trap_grid(const float* wf, int64_t n, int NT, bool full, const TrapGridDev* dP, float* out, hipStream_t st);
+hipError_t launch_fir_grid(const float* wf, int64_t n, int NT, bool full, const FirGridDev* dP, float* out, hipStream_t st);
 }  // namespace ldsp
 
 using namespace ldsp;
@@ -91,7 +92,7 @@ int ldsp_ctx_destroy(ldsp_ctx* c) {
   if (!c) return LDSP_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_aux); (void)hipFree(c->d_coef); (void)hipFree(c->d_grid);
+  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_aux); (void)hipFree(c->d_coef); (void)hipFree(c->d_grid); (void)hipFree(c->d_fir_grid);
   (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); (void)hipEventDestroy(c->evm);
   (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -424,11 +425,58 @@ int ldsp_trap_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapg
     d.offs[g] = offsets ? (float)(offsets[g] / p->dt) : 0.f;
   }
   HIP_TRY(hipSetDevice(c->device));
-  if (!c->d_grid) HIP_TRY(hipMalloc(&c->d_grid, sizeof(TrapGridDev)));
+  if (!c->d_grid) HIP_TRY(hipMalloc(&c->d_grid, sizeof(TrapGridDev) > sizeof(FirGridDev) ? sizeof(TrapGridDev) : sizeof(FirGridDev)));
   HIP_TRY(hipMemcpyAsync(c->d_grid, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));   // the staging block is reused by the next call
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   HIP_TRY(launch_trap_grid(wf, n, d.NT, L == 16 * d.NT, reinterpret_cast<const TrapGridDev*>(c->d_grid), out, c->stream));
+  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
+  return LDSP_OK;
+}
+
+int ldsp_fir_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgrid_params* p, int32_t G, int32_t Lf, const double* taps,
+                      const double* offsets, float* out) {
+  if (!c || !p || !taps || !out) return fail(LDSP_ERR_INVALID_ARG, "ldsp_fir_grid_run: NULL argument");
+  int rc = ldsp_check_batch(c, wf, n, p->L, "ldsp_fir_grid_run");
+  if (rc || n == 0) return rc;
+  const int L = p->L;
+  if (G < 1 || G > LDSP_MAX_GRID) return fail(LDSP_ERR_UNSUPPORTED, "grid of %d points (1..%d supported)", G, LDSP_MAX_GRID);
+  if (Lf < 1 || Lf > LDSP_MAX_FIR_TAPS || Lf + p->sig_est.npts > L + 1) return fail(LDSP_ERR_WINDOW, "FIR of %d taps does not fit a trace of %d samples", Lf, L);
+  if (!(p->dt > 0)) return fail(LDSP_ERR_INVALID_ARG, "dt must be positive");
+  if (!check_window(p->bl_from, p->bl_until, L)) return fail(LDSP_ERR_WINDOW, "bl_window [%d,%d] outside trace", p->bl_from, p->bl_until);
+  if (p->pick_mode != 0 && p->pick_mode != 1) return fail(LDSP_ERR_INVALID_ARG, "pick_mode must be 0 or 1");
+  if (p->pick_mode == 1 && (!offsets || p->tx_mintot < 1)) return fail(LDSP_ERR_INVALID_ARG, "mode 1 needs offsets and tx_mintot >= 1");
+  FirGridDev d;
+  memset(&d, 0, sizeof d);
+  d.L = L; d.G = G; d.Lf = Lf; d.pick_mode = p->pick_mode; d.tx_mintot = p->tx_mintot;
+  d.NT = 64;
+  while (d.NT * 16 < L) d.NT *= 2;
+  if (d.NT > 1024) return fail(LDSP_ERR_UNSUPPORTED, "trace length %d: at most 16384 samples here", L);
+  d.t_first = (float)p->t_first; d.dt = (float)p->dt;
+  d.bl = make_win(p->bl_from, p->bl_until);
+  d.pz_c = (float)p->pz_c; d.pz_c64 = p->pz_c;
+  if (!make_est(p->sig_est, d.est)) return fail(LDSP_ERR_UNSUPPORTED, "PolynomialDNI(%d, %d points) unsupported", p->sig_est.degree, p->sig_est.npts);
+  const double pos = (p->pick_time - p->t_first) / p->dt, fl = std::floor(pos);
+  d.pick_ip = (int)fl; d.pick_fp = (float)(pos - fl);
+  for (int g = 0; g < G; ++g) d.offs[g] = offsets ? (float)(offsets[g] / p->dt) : 0.f;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t ntap = (size_t)G * (size_t)Lf;
+  if (ntap > c->fir_grid_cap) {   // grow-only tap buffer
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_fir_grid); c->d_fir_grid = nullptr; c->fir_grid_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_fir_grid, ntap * sizeof(float)));
+    c->fir_grid_cap = ntap;
+  }
+  std::vector<float> rev(ntap);   // reversed: out[k] = sum_j h[j] y[k+Lf-1-j] = sum_j c[j] y[k+j], c[j] = h[Lf-1-j]
+  for (int g = 0; g < G; ++g)
+    for (int j = 0; j < Lf; ++j) rev[(size_t)g * Lf + j] = (float)taps[(size_t)g * Lf + (Lf - 1 - j)];
+  d.taps = c->d_fir_grid;
+  if (!c->d_grid) HIP_TRY(hipMalloc(&c->d_grid, sizeof(TrapGridDev) > sizeof(FirGridDev) ? sizeof(TrapGridDev) : sizeof(FirGridDev)));
+  HIP_TRY(hipMemcpyAsync(c->d_fir_grid, rev.data(), ntap * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_grid, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));   // the staging vectors die at return
+  if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(launch_fir_grid(wf, n, d.NT, L == 16 * d.NT, reinterpret_cast<const FirGridDev*>(c->d_grid), out, c->stream));
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
   return LDSP_OK;
 }

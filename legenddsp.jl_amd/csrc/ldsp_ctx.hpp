@@ -28,6 +28,8 @@ struct ldsp_ctx {
   float* d_hz = nullptr;
   float* d_aux = nullptr;   // [aux_cap][4] kernel 1 -> kernel 2 hand-over (blmean, t50 position)
   int64_t aux_cap = 0;
+  float* d_fir_grid = nullptr;   // [fir_grid_cap] taps of ldsp_fir_grid_run (grow-only)
+  size_t fir_grid_cap = 0;
   void* d_grid = nullptr;   // TrapGridDev of ldsp_trap_grid_run (allocated on first use)
   float* d_coef = nullptr;  // [LDSP_MAX_FIR_TAPS] staging for functor coefficients / small tables
   int cusp_direct = 0;

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _abi, _lib
-from .config import DSPConfig, WindowError, nsamples, trap_samples, window_index
+from .config import DSPConfig, WindowError, cuspzac_lowered, nsamples, trap_samples, window_index
 from .routines import ArrayOfRDWaveforms, _as_device_f32
 
 
@@ -70,3 +70,74 @@ def dsp_trap_ft_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: f
     traps = [trap_samples(rt, ft, wvfs.dt) for ft in grid]
     offsets = [float(rt) + float(ft) / 2 for ft in grid]
     return trap_grid_run(wvfs.signal, p, traps, offsets, ctx)
+
+
+def fir_grid_run(wf: torch.Tensor, params: _abi.TrapGridParams, taps: np.ndarray, offsets=None, ctx: _lib.Context = None) -> torch.Tensor:
+    """`ldsp_fir_grid_run`: taps [G, Lf] float64 (host, FIR order) -> [G, n] float32 device tensor."""
+    if not wf.is_cuda:
+        raise _lib.LdspError(-103, "fir_grid_run needs a device-resident waveform tensor (no CPU fallback)")
+    ctx = ctx or _lib.default_context(wf.device.index)
+    n, L = wf.shape
+    if L != params.L:
+        raise ValueError(f"waveform length {L} != params.L {params.L}")
+    wf = _as_device_f32(wf, wf.device)
+    taps = np.ascontiguousarray(taps, dtype=np.float64)
+    G, Lf = taps.shape
+    offs = None
+    if offsets is not None:
+        offs = np.ascontiguousarray(offsets, dtype=np.float64)
+        assert len(offs) == G
+    out = torch.empty((G, n), dtype=torch.float32, device=wf.device)
+    ctx.bind_stream()
+    _lib.check(_lib.lib().ldsp_fir_grid_run(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params), G, Lf, taps.ctypes.data_as(C.c_void_p),
+                                            offs.ctypes.data_as(C.c_void_p) if offs is not None else None, C.c_void_p(out.data_ptr())))
+    return out
+
+
+_TAU_OFF = 10000000.0 * 1000.0   # 1e7 us in ns: "switch off the CR filter" (dsp_filter_optimization.jl:153)
+
+
+def cuspzac_grid_taps(kind: str, pairs, length: float, dt: float) -> np.ndarray:
+    """Coefficients of CUSPChargeFilter / ZACChargeFilter(rt, ft, tau_off, length, length/dt) for every (rt, ft) pair."""
+    fn = _lib.lib().ldsp_cusp_coeffs if kind == "cusp" else _lib.lib().ldsp_zac_coeffs
+    rows = []
+    for rt, ft in pairs:
+        cz = cuspzac_lowered(rt, ft, _TAU_OFF, length, float(length) / float(dt), dt)
+        h = np.empty(cz.length, dtype=np.float64)
+        _lib.check(fn(C.byref(cz), h.ctypes.data_as(C.c_void_p)))
+        rows.append(h)
+    return np.stack(rows)
+
+
+def _cz_rt(kind, wvfs, config, tau, ft, ctx):
+    grid = list(getattr(config, f"e_grid_rt_{kind}"))
+    length = getattr(config, f"flt_length_{kind}")
+    p = lower_trap_grid(config, tau, wvfs.nsamples, wvfs.t_first, wvfs.dt, 0, getattr(config, f"enc_pickoff_{kind}"))
+    return fir_grid_run(wvfs.signal, p, cuspzac_grid_taps(kind, [(rt, ft) for rt in grid], length, wvfs.dt), None, ctx)
+
+
+def _cz_ft(kind, wvfs, config, tau, rt, ctx):
+    grid = list(getattr(config, f"e_grid_ft_{kind}"))
+    length = getattr(config, f"flt_length_{kind}")
+    p = lower_trap_grid(config, tau, wvfs.nsamples, wvfs.t_first, wvfs.dt, 1)
+    return fir_grid_run(wvfs.signal, p, cuspzac_grid_taps(kind, [(rt, ft) for ft in grid], length, wvfs.dt), [float(length) / 2] * len(grid), ctx)
+
+
+def dsp_cusp_rt_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, ft: float = 2000.0, ctx=None) -> torch.Tensor:
+    """ENC grid over `config.e_grid_rt_cusp` at flat top `ft`, pick-off `config.enc_pickoff_cusp` (reference :145-181)."""
+    return _cz_rt("cusp", wvfs, config, tau, ft, ctx)
+
+
+def dsp_zac_rt_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, ft: float = 2000.0, ctx=None) -> torch.Tensor:
+    """The same with ZACChargeFilter (reference :193-229)."""
+    return _cz_rt("zac", wvfs, config, tau, ft, ctx)
+
+
+def dsp_cusp_ft_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, rt: float, ctx=None) -> torch.Tensor:
+    """Energy grid over `config.e_grid_ft_cusp` at rise time `rt`, pick-off t50 + flt_length_cusp/2 (reference :286-324)."""
+    return _cz_ft("cusp", wvfs, config, tau, rt, ctx)
+
+
+def dsp_zac_ft_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, rt: float, ctx=None) -> torch.Tensor:
+    """The same with ZACChargeFilter (reference :336-374)."""
+    return _cz_ft("zac", wvfs, config, tau, rt, ctx)

@@ -252,3 +252,26 @@ def trap_grid(wf, params, traps, offsets=None):
             t = params.pick_time if params.pick_mode == 0 else t50 + offsets[g]
             out[g, i] = signal_estimator(f, t, params.sig_est.npts, params.sig_est.degree, tf, dt)
     return out
+
+
+def fir_grid(wf, params, taps, offsets=None):
+    """CPU restatement of ldsp_fir_grid_run (reference src/dsp_filter_optimization.jl:145-229, 286-374): as trap_grid
+    with an arbitrary FIR per grid point (taps [G, Lf], FIR order, valid mode, trailing time axis)."""
+    wf = np.asarray(wf, dtype=np.float64)
+    taps = np.asarray(taps, dtype=np.float64)
+    n, L = wf.shape
+    t0, dt = params.t_first, params.dt
+    G, Lf = taps.shape
+    out = np.empty((G, n))
+    for i in range(n):
+        x = wf[i] - signalstats(wf[i], params.bl_from, params.bl_until, t0, dt)["mean"]
+        y = invcr(x, params.pz_c)
+        if params.pick_mode == 1:
+            r = intersect(y, 0.5 * y.max(), params.tx_mintot, t0, dt)
+            t50 = 0.0 if np.isnan(r["x"]) else r["x"]
+        for g in range(G):
+            f = fir(y, taps[g])
+            tf = t0 + dt * (Lf - 1)
+            t = params.pick_time if params.pick_mode == 0 else t50 + offsets[g]
+            out[g, i] = signal_estimator(f, t, params.sig_est.npts, params.sig_est.degree, tf, dt)
+    return out

@@ -49,3 +49,29 @@ def test_grid_argument_checks():
         ldsp.trap_grid_run(wvfs.signal, p, [ldsp._abi.Trap(5000, 10, 5000)])
     with pytest.raises(ldsp.LdspError):   # more grid points than the kernel holds
         ldsp.trap_grid_run(wvfs.signal, p, [ldsp._abi.Trap(10, 2, 10)] * (ldsp._abi.LDSP_MAX_GRID + 1))
+
+
+@pytest.mark.parametrize("kind", ["cusp", "zac"])
+def test_cusp_zac_grid_scans_match_oracle(orc, kind):
+    """dsp_{cusp,zac}_rt_optimization and _ft_optimization (direct-form FIR at the estimator window) vs the oracle."""
+    cfg = ldsp.reference_test_icpc_config()
+    wvfs = ldsp.ArrayOfRDWaveforms(ldsp.synth.hpge_batch(12, L, device="cuda", seed=41), 0.0, 16.0)
+    length = getattr(cfg, f"flt_length_{kind}")
+    # rise-time grid at a fixed pick-off (ENC scan)
+    grid = list(getattr(cfg, f"e_grid_rt_{kind}"))[::6]            # a subset keeps the oracle's direct convolutions short
+    p0 = ldsp.lower_trap_grid(cfg, 500 * ldsp.us, L, 0.0, 16.0, 0, getattr(cfg, f"enc_pickoff_{kind}"))
+    taps = ldsp.cuspzac_grid_taps(kind, [(rt, 2 * ldsp.us) for rt in grid], length, 16.0)
+    out = ldsp.fir_grid_run(wvfs.signal, p0, taps).cpu().numpy()
+    ora = orc.fir_grid(wvfs.signal.cpu().numpy(), p0, taps)
+    np.testing.assert_allclose(out, ora, rtol=3e-5, atol=0.1)
+    # flat-top grid at t50 + length/2 (energy scan) through the routine itself
+    fn = ldsp.dsp_cusp_ft_optimization if kind == "cusp" else ldsp.dsp_zac_ft_optimization
+    full = fn(wvfs, cfg, 500 * ldsp.us, 8 * ldsp.us).cpu().numpy()
+    gft = list(getattr(cfg, f"e_grid_ft_{kind}"))
+    assert full.shape == (len(gft), 12)
+    p1 = ldsp.lower_trap_grid(cfg, 500 * ldsp.us, L, 0.0, 16.0, 1)
+    sel = [0, len(gft) // 2, len(gft) - 1]
+    taps1 = ldsp.cuspzac_grid_taps(kind, [(8 * ldsp.us, gft[j]) for j in sel], length, 16.0)
+    ora1 = orc.fir_grid(wvfs.signal.cpu().numpy(), p1, taps1, [length / 2] * len(sel))
+    np.testing.assert_allclose(full[sel], ora1, rtol=3e-5, atol=0.1)
+    assert np.all(full > 100.0)   # energies of the pulses

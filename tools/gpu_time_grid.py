@@ -8,7 +8,9 @@ cfg = ldsp.reference_test_icpc_config()
 wvfs = ldsp.ArrayOfRDWaveforms(ldsp.synth.hpge_batch(n, L, device="cuda"), 0.0, 16.0)
 ctx = ldsp.default_context(); ctx.enable_timing(True)
 for name, fn in (("dsp_trap_rt_optimization", lambda: ldsp.dsp_trap_rt_optimization(wvfs, cfg, 500 * ldsp.us, ctx=ctx)),
-                 ("dsp_trap_ft_optimization", lambda: ldsp.dsp_trap_ft_optimization(wvfs, cfg, 500 * ldsp.us, 8 * ldsp.us, ctx=ctx))):
+                 ("dsp_trap_ft_optimization", lambda: ldsp.dsp_trap_ft_optimization(wvfs, cfg, 500 * ldsp.us, 8 * ldsp.us, ctx=ctx)),
+                 ("dsp_cusp_rt_optimization", lambda: ldsp.dsp_cusp_rt_optimization(wvfs, cfg, 500 * ldsp.us, ctx=ctx)),
+                 ("dsp_zac_ft_optimization", lambda: ldsp.dsp_zac_ft_optimization(wvfs, cfg, 500 * ldsp.us, 8 * ldsp.us, ctx=ctx))):
     out = fn(); torch.cuda.synchronize()
     ms = min((fn(), ctx.last_kernel_ms())[1] for _ in range(3))
     G = out.shape[0]
