@@ -264,6 +264,16 @@ int ldsp_trap_grid_run(ldsp_ctx* ctx, const float* wf, int64_t n, const ldsp_tra
 int ldsp_fir_grid_run(ldsp_ctx* ctx, const float* wf, int64_t n, const ldsp_trapgrid_params* p, int32_t G, int32_t Lf,
                       const double* taps, const double* offsets, float* out);
 
+/* dsp_sg_optimization (src/dsp_filter_optimization.jl:393-441): baseline statistics, pole-zero, t50, the energy
+ * e = SignalEstimator(Trapezoid(rt, ft) output, t50 + rt + ft/2), and for every window length of the grid the
+ * interpolated maximum (get_wvf_maximum) of the Savitzky-Golay derivative inside the current window.
+ * p->pick_mode must be 1; trap_offset = rt + ft/2 (time units).  npts[W], from[W], until[W]: SG points and the
+ * current window on each filter's own output axis (0-based samples).  Outputs (device, any may be NULL):
+ * amax [W][n], energy / t50_us / blmean / blslope [n]; A/E = amax / energy is the caller's division. */
+int ldsp_sg_grid_run(ldsp_ctx* ctx, const float* wf, int64_t n, const ldsp_trapgrid_params* p, const ldsp_trap* trap,
+                     double trap_offset, double unit_per_us, int32_t W, const int32_t* npts, int32_t degree, const int32_t* from,
+                     const int32_t* until, float* amax, float* energy, float* t50_us, float* blmean, float* blslope);
+
 /* BASELINE config 2: the e_10410 column path only — signalstats(bl) -> shift
  * -> InvCRFilter -> TrapezoidalChargeFilter(10us,4us) -> maximum
  * (src/dsp_icpc.jl:102-105,119-120,147-148).  Writes blmean[n], e_10410[n]. */

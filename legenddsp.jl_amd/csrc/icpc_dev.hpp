@@ -81,6 +81,20 @@ struct FirGridDev {
   const float* taps;   // device, [G][Lf], taps REVERSED (correlation form: out[k] = sum_j c[j] y[k+j])
 };
 
+// SG window-length grid scan (ldsp_sg_grid_run)
+struct SgGridDev {
+  int32_t L, NT, W, tx_mintot;
+  float t_first, dt, inv_unit_per_us;
+  WinDev bl;
+  float pz_c;
+  double pz_c64;
+  EstDev est;
+  TrapDev trap;
+  float trap_off;            // rt + ft/2 in samples
+  int32_t np[32], from[32], until[32];
+  float c[32][LDSP_MAX_SG_PTS];   // correlation taps per grid point
+};
+
 struct IcpcDev {
   int32_t L, NT, R;   // trace length; threads and float4 rows per thread of the launch
   float t_first, dt, unit_per_us, inv_unit_per_us;

@@ -1684,6 +1684,162 @@ hipError_t launch_fir_grid(const float* wf, int64_t n, int NT, bool full, const 
 #undef LDSP_CASE
 }
 
+// ---------------------------------------------------------------------------
+// dsp_sg_optimization (reference src/dsp_filter_optimization.jl:393-441): front end as trap_grid_kernel (blmean +
+// slope, pole-zero, T, t50), the trapezoid energy at t50 + rt + ft/2, then one wave per SG window length: the
+// derivative filter only inside the current window (lane-strided), first-occurrence arg-max, parabola vertex.
+template <int NT, int R, bool FULL>
+__global__ void __launch_bounds__(NT)
+sg_grid_kernel(const float* __restrict__ wf, const SgGridDev* __restrict__ Pp, float* __restrict__ amax, float* __restrict__ energy,
+               float* __restrict__ t50_us, float* __restrict__ o_blmean, float* __restrict__ o_blslope, int64_t n) {
+  constexpr int NW = NT / 64, SP = 4 * R, Lp = NT * SP, NWORDS = Lp / 32;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const SgGridDev& P = *Pp;
+  const int L = FULL ? Lp : P.L, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  float* T = reinterpret_cast<float*>(smem_raw);                                   // [Lp+64]
+  float* Y = T + Lp + 64;                                                           // [Lp+64]
+  uint32_t* bm = reinterpret_cast<uint32_t*>(Y + Lp + 64);                          // [NWORDS]
+  double* part = reinterpret_cast<double*>(smem_raw + (size_t)(2 * Lp + 128 + NWORDS) * 4);   // [2][R*NW]
+  double* wsum = part + 2 * R * NW;                                                 // [3][NW]
+  float* estB = reinterpret_cast<float*>(wsum + 3 * NW);                            // [EST_TBL]
+  uint32_t* slot = reinterpret_cast<uint32_t*>(estB + EST_TBL);                     // [4]
+  const float* w = wf + (size_t)blockIdx.x * (size_t)L;
+  float x[R][4];
+  load_trace_s4<NT, R, FULL>(w, L, tid, x);
+  for (int i = tid; i < EST_TBL; i += NT) estB[i] = P.est.B[i];
+  if (tid < 64) { T[Lp + tid] = 0.f; Y[Lp + tid] = 0.f; }
+  if (tid == 0) { slot[0] = 0u; slot[1] = 0x7fffffffu; slot[2] = 0u; }
+  const float pv_bl = w[P.bl.from];
+  WinAccF bl = {0, 0, 0};
+  const float fic = (float)P.bl.ic;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i0 = 4 * (tid + NT * r);
+    winf_accum4(bl, P.bl, i0, (float)i0 - fic, pv_bl, x[r][0], x[r][1], x[r][2], x[r][3]);
+  }
+  win_publish<NW>(bl, wsum, 0);
+  __syncthreads();
+  const float blmean = (float)((double)pv_bl + win_collect1<NW>(wsum, 0) * P.bl.inv_n);
+  if (tid == 0) {
+    float m_, sg_, sl_, of_;
+    win_finish(win_collect<NW>(wsum, 0), P.bl, pv_bl, P.t_first, P.dt, &m_, &sg_, &sl_, &of_);
+    if (o_blmean) o_blmean[blockIdx.x] = blmean;
+    if (o_blslope) o_blslope[blockIdx.x] = sl_;
+  }
+  float tot[R];
+  double off[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i0 = 4 * (tid + NT * r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[r][e] = (i0 + e < L) ? x[r][e] - blmean : 0.f;
+    tot[r] = (x[r][0] + x[r][1]) + (x[r][2] + x[r][3]);
+  }
+  s4_exscan_sum<NT, R>(tot, off, part, nullptr);
+  float ymax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i0 = 4 * (tid + NT * r);
+    const float coff = (float)(P.pz_c64 * off[r]);
+    float run = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      run += x[r][e];
+      x[r][e] = (i0 + e < L) ? (x[r][e] + coff) + P.pz_c * run : 0.f;
+      ymax = vmax(ymax, (i0 + e < L) ? x[r][e] : -INFINITY);
+    }
+    tot[r] = (x[r][0] + x[r][1]) + (x[r][2] + x[r][3]);
+    *reinterpret_cast<float4*>(&Y[i0]) = make_float4(x[r][0], x[r][1], x[r][2], x[r][3]);
+  }
+  ymax = wave_max_all(ymax);
+  if (lane == 0) atomicMax(&slot[0], ford(ymax));
+  double tot_all;
+  s4_exscan_sum<NT, R>(tot, off, part + R * NW, &tot_all);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double run = off[r];
+    float4 t;
+    float* pt = &t.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pt[e] = (float)run; run += (double)x[r][e]; }
+    *reinterpret_cast<float4*>(&T[4 * (tid + NT * r)]) = t;
+  }
+  if (tid == 0) T[Lp] = (float)tot_all;
+  // t50 = get_threshold(wvfs, 0.5 * maximum; mintot)   :421
+  const float thr = 0.5f * ford_inv(slot[0]);
+#pragma unroll
+  for (int m = 0; m < SP; ++m) {
+    const int k = tid + NT * m;
+    const unsigned long long bq = __ballot(k < L && Y[k] >= thr);
+    if (lane == 0) *reinterpret_cast<unsigned long long*>(&bm[(NT >> 5) * m + 2 * wave]) = bq;
+  }
+  __syncthreads();
+  for (int wd = tid; wd < NWORDS; wd += NT) {
+    int c, f;
+    intersect_word(bm, wd, NWORDS, P.tx_mintot, &c, &f);
+    if (c) { atomicAdd(&slot[2], (uint32_t)c); atomicMin(reinterpret_cast<int*>(&slot[1]), f); }
+  }
+  __syncthreads();
+  Pos base;
+  float t50 = 0.f;
+  if (slot[2] > 0) {
+    const int p = (int)slot[1];
+    const float yl = Y[p - 1], yh = Y[p];
+    base.ip = p - 1; base.fp = (thr - yl) / (yh - yl);
+    t50 = (P.t_first + P.dt * ((float)base.ip + base.fp)) * P.inv_unit_per_us;
+  } else {
+    base.ip = 0; base.fp = -P.t_first / P.dt;
+    base = pos_norm(base);
+  }
+  if (tid == 0 && t50_us) t50_us[blockIdx.x] = t50;
+  if (wave == NW - 1) {   // energy: the last wave (the grid loop below starts at wave 0)
+    Pos p = pos_add(base, P.trap_off);
+    p.ip -= (P.trap.flen - 1);
+    const TrapDev tr = P.trap;
+    const float e = estimate(P.est, estB, p, L - tr.flen + 1, [&](int i) { return trap_at(T, i, tr); });
+    if (lane == 0 && energy) energy[blockIdx.x] = e;
+  }
+  for (int g = wave; g < P.W; g += NW) {
+    const int np = P.np[g], from = P.from[g], until = P.until[g];
+    const float* c = P.c[g];
+    auto sg_at = [&](int k) { float a = 0.f; for (int i = 0; i < np; ++i) a = fmaf(c[i], Y[k + i], a); return a; };
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int k = from + lane; k <= until; k += 64) {
+      const float v = sg_at(k);
+      if (v > bv) { bv = v; bi = k; }
+    }
+    unsigned long long best = wave_max_u64(pack_vi(bv, bi));
+    float v; int i;
+    unpack_vi(best, &v, &i);
+    if (i > from && i < until) v = extrema3points(sg_at(i - 1), sg_at(i), sg_at(i + 1));   // get_wvf_maximum (src/interpolation.jl:30-46)
+    if (lane == 0 && amax) amax[(size_t)g * (size_t)n + blockIdx.x] = v;
+  }
+}
+
+template <int NT, int R, bool FULL>
+static hipError_t launch_sg_grid_t(const float* wf, int64_t n, const SgGridDev* dP, float* amax, float* energy, float* t50, float* blm, float* bls,
+                                   hipStream_t st) {
+  constexpr int NW = NT / 64, Lp = 16 * NT;
+  const size_t smem = (size_t)(2 * Lp + 128 + Lp / 32) * 4 + (2 * R * NW + 3 * NW) * 8 + EST_TBL * 4 + 32;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sg_grid_kernel<NT, R, FULL>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((sg_grid_kernel<NT, R, FULL>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, amax, energy, t50, blm, bls, n);
+  return hipGetLastError();
+}
+hipError_t launch_sg_grid(const float* wf, int64_t n, int NT, bool full, const SgGridDev* dP, float* amax, float* energy, float* t50, float* blm,
+                          float* bls, hipStream_t st) {
+#define LDSP_CASE(N)                                                                                   \
+  case N:                                                                                              \
+    return full ? launch_sg_grid_t<N, 4, true>(wf, n, dP, amax, energy, t50, blm, bls, st)             \
+                : launch_sg_grid_t<N, 4, false>(wf, n, dP, amax, energy, t50, blm, bls, st);
+  switch (NT) {
+    LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
+    default: return hipErrorInvalidValue;
+  }
+#undef LDSP_CASE
+}
+
 // Largest dynamic LDS size that still lets two workgroups share a CU (160 KiB, 1280-byte granules)
 constexpr size_t LDS_TWO_PER_CU = 80640;
 

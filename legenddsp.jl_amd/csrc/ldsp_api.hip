@@ -22,6 +22,8 @@ hipError_t launch_icpc(const float* wf, int64_t n, int NT, bool full, const Icpc
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 size_t icpc_smem_bytes(int NT);
 hipError_t launch_trap_grid(const float* wf, int64_t n, int NT, bool full, const TrapGridDev* dP, float* out, hipStream_t st);
+hipError_t launch_sg_grid(const float* wf, int64_t n, int NT, bool full, const SgGridDev* dP, float* amax, float* energy, float* t50, float* blm,
+                          float* bls, hipStream_t st);
 hipError_t launch_fir_grid(const float* wf, int64_t n, int NT, bool full, const FirGridDev* dP, float* out, hipStream_t st);
 }  // namespace ldsp
 
@@ -92,7 +94,7 @@ int ldsp_ctx_destroy(ldsp_ctx* c) {
   if (!c) return LDSP_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_aux); (void)hipFree(c->d_coef); (void)hipFree(c->d_grid); (void)hipFree(c->d_fir_grid);
+  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_aux); (void)hipFree(c->d_coef); (void)hipFree(c->d_grid); (void)hipFree(c->d_fir_grid); (void)hipFree(c->d_sg_grid);
   (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); (void)hipEventDestroy(c->evm);
   (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -463,7 +465,7 @@ int ldsp_fir_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgr
   const size_t ntap = (size_t)G * (size_t)Lf;
   if (ntap > c->fir_grid_cap) {   // grow-only tap buffer
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(c->d_fir_grid); c->d_fir_grid = nullptr; c->fir_grid_cap = 0;
+    (void)hipFree(c->d_fir_grid); (void)hipFree(c->d_sg_grid); c->d_fir_grid = nullptr; c->fir_grid_cap = 0;
     HIP_TRY(hipMalloc(&c->d_fir_grid, ntap * sizeof(float)));
     c->fir_grid_cap = ntap;
   }
@@ -477,6 +479,51 @@ int ldsp_fir_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgr
   HIP_TRY(hipStreamSynchronize(c->stream));   // the staging vectors die at return
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   HIP_TRY(launch_fir_grid(wf, n, d.NT, L == 16 * d.NT, reinterpret_cast<const FirGridDev*>(c->d_grid), out, c->stream));
+  if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
+  return LDSP_OK;
+}
+
+int ldsp_sg_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgrid_params* p, const ldsp_trap* trap, double trap_offset,
+                     double unit_per_us, int32_t W, const int32_t* npts, int32_t degree, const int32_t* from, const int32_t* until, float* amax,
+                     float* energy, float* t50_us, float* blmean, float* blslope) {
+  if (!c || !p || !trap || !npts || !from || !until) return fail(LDSP_ERR_INVALID_ARG, "ldsp_sg_grid_run: NULL argument");
+  int rc = ldsp_check_batch(c, wf, n, p->L, "ldsp_sg_grid_run");
+  if (rc || n == 0) return rc;
+  const int L = p->L;
+  if (W < 1 || W > 32) return fail(LDSP_ERR_UNSUPPORTED, "grid of %d window lengths (1..32 supported)", W);
+  if (!(p->dt > 0) || !(unit_per_us > 0)) return fail(LDSP_ERR_INVALID_ARG, "dt and unit_per_us must be positive");
+  if (p->pick_mode != 1 || p->tx_mintot < 1) return fail(LDSP_ERR_INVALID_ARG, "ldsp_sg_grid_run picks off at t50: pick_mode 1, tx_mintot >= 1");
+  if (!check_window(p->bl_from, p->bl_until, L)) return fail(LDSP_ERR_WINDOW, "bl_window [%d,%d] outside trace", p->bl_from, p->bl_until);
+  if (!trap_ok(*trap, L)) return fail(LDSP_ERR_WINDOW, "trapezoid does not fit");
+  static_assert(sizeof(SgGridDev) < 64 * 1024, "parameter block");
+  std::vector<unsigned char> buf(sizeof(SgGridDev), 0);
+  SgGridDev& d = *reinterpret_cast<SgGridDev*>(buf.data());
+  d.L = L; d.W = W; d.tx_mintot = p->tx_mintot;
+  d.NT = 64;
+  while (d.NT * 16 < L) d.NT *= 2;
+  if (d.NT > 1024) return fail(LDSP_ERR_UNSUPPORTED, "trace length %d: at most 16384 samples here", L);
+  d.t_first = (float)p->t_first; d.dt = (float)p->dt; d.inv_unit_per_us = (float)(1.0 / unit_per_us);
+  d.bl = make_win(p->bl_from, p->bl_until);
+  d.pz_c = (float)p->pz_c; d.pz_c64 = p->pz_c;
+  if (!make_est(p->sig_est, d.est)) return fail(LDSP_ERR_UNSUPPORTED, "PolynomialDNI(%d, %d points) unsupported", p->sig_est.degree, p->sig_est.npts);
+  d.trap = make_trap(*trap);
+  d.trap_off = (float)(trap_offset / p->dt);
+  for (int g = 0; g < W; ++g) {
+    const int np = npts[g];
+    if (np < 1 || np > LDSP_MAX_SG_PTS || (np & 1) == 0 || np <= degree || np > L)
+      return fail(LDSP_ERR_UNSUPPORTED, "Savitzky-Golay window of %d points (degree %d) unsupported", np, degree);
+    if (!check_window(from[g], until[g], L - np + 1)) return fail(LDSP_ERR_WINDOW, "current window [%d,%d] outside the SG output axis", from[g], until[g]);
+    std::vector<double> cc;
+    if (!hm::sg_corr_coeffs(np, degree, 1, cc)) return fail(LDSP_ERR_INVALID_ARG, "Savitzky-Golay coefficients");
+    d.np[g] = np; d.from[g] = from[g]; d.until[g] = until[g];
+    for (int i = 0; i < np; ++i) d.c[g][i] = (float)cc[i];
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->d_sg_grid) HIP_TRY(hipMalloc(&c->d_sg_grid, sizeof(SgGridDev)));
+  HIP_TRY(hipMemcpyAsync(c->d_sg_grid, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(launch_sg_grid(wf, n, d.NT, L == 16 * d.NT, reinterpret_cast<const SgGridDev*>(c->d_sg_grid), amax, energy, t50_us, blmean, blslope, c->stream));
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
   return LDSP_OK;
 }

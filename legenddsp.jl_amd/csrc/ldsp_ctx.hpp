@@ -30,6 +30,7 @@ struct ldsp_ctx {
   int64_t aux_cap = 0;
   float* d_fir_grid = nullptr;   // [fir_grid_cap] taps of ldsp_fir_grid_run (grow-only)
   size_t fir_grid_cap = 0;
+  void* d_sg_grid = nullptr;  // SgGridDev of ldsp_sg_grid_run
   void* d_grid = nullptr;   // TrapGridDev of ldsp_trap_grid_run (allocated on first use)
   float* d_coef = nullptr;  // [LDSP_MAX_FIR_TAPS] staging for functor coefficients / small tables
   int cusp_direct = 0;

@@ -13,8 +13,8 @@ import numpy as np
 import torch
 
 from . import _abi, _lib
-from .config import DSPConfig, WindowError, cuspzac_lowered, nsamples, trap_samples, window_index
-from .routines import ArrayOfRDWaveforms, _as_device_f32
+from .config import DSPConfig, WindowError, cuspzac_lowered, get_fltpars, nsamples, sg_npoints, trap_samples, window_index, UNIT_PER_US
+from .routines import ArrayOfRDWaveforms, Table, _as_device_f32
 
 
 def lower_trap_grid(config: DSPConfig, tau: float, L: int, t_first: float, dt: float, pick_mode: int, pick_time: float = 0.0):
@@ -141,3 +141,42 @@ def dsp_cusp_ft_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: f
 def dsp_zac_ft_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, rt: float, ctx=None) -> torch.Tensor:
     """The same with ZACChargeFilter (reference :336-374)."""
     return _cz_ft("zac", wvfs, config, tau, rt, ctx)
+
+
+def dsp_sg_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, pars_filter: dict, f_evaluate_qc=None, ctx=None) -> Table:
+    """`dsp_sg_optimization(wvfs, config, tau, pars_filter)` (reference :393-441): A/E over the Savitzky-Golay window
+    lengths `config.a_grid_wl_sg`.  Columns: aoe [W, n], energy, blmean, blslope, t50 (us), qc_label (-1: no classifier)."""
+    if f_evaluate_qc is not None:
+        raise NotImplementedError("the SVM QC classifier is out of scope (DESIGN.md section 6)")
+    x = wvfs.signal
+    if not x.is_cuda:
+        raise _lib.LdspError(-103, "dsp_sg_optimization needs device-resident waveforms (no CPU fallback)")
+    ctx = ctx or _lib.default_context(x.device.index)
+    x = _as_device_f32(x, x.device)
+    n, L = x.shape
+    dt, t0 = wvfs.dt, wvfs.t_first
+    rt, ft = get_fltpars(pars_filter, "trap", config)
+    p = lower_trap_grid(config, tau, L, t0, dt, 1)
+    grid = list(config.a_grid_wl_sg)
+    W = len(grid)
+    npts = np.array([sg_npoints(wl, dt) for wl in grid], dtype=np.int32)
+    # current window on each filter's output axis (trailing alignment: its first time is t0 + (npts-1) dt)
+    frm = np.array([window_index(config.current_window.left, t0 + (m - 1) * dt, dt) for m in npts], dtype=np.int32)
+    until = np.array([window_index(config.current_window.right, t0 + (m - 1) * dt, dt) for m in npts], dtype=np.int32)
+    for a, b, m in zip(frm, until, npts):
+        if not (0 <= a <= b <= L - m):
+            raise WindowError(f"current_window [{a},{b}] outside the output of a {m}-point Savitzky-Golay filter")
+    dev = x.device
+    amax = torch.empty((W, n), dtype=torch.float32, device=dev)
+    energy, t50, blmean, blslope = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
+    trap = trap_samples(rt, ft, dt)
+    ctx.bind_stream()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(_lib.lib().ldsp_sg_grid_run(ctx.handle, vp(x), n, C.byref(p), C.byref(trap), float(rt) + float(ft) / 2, UNIT_PER_US, W,
+                                           npts.ctypes.data_as(C.c_void_p), int(config.sg_flt_degree), frm.ctypes.data_as(C.c_void_p),
+                                           until.ctypes.data_as(C.c_void_p), vp(amax), vp(energy), vp(t50), vp(blmean), vp(blslope)))
+    res = Table()
+    res["aoe"] = amax / energy[None, :]
+    res["energy"], res["blmean"], res["blslope"], res["t50"] = energy, blmean, blslope, t50
+    res["qc_label"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    return res

@@ -275,3 +275,27 @@ def fir_grid(wf, params, taps, offsets=None):
             t = params.pick_time if params.pick_mode == 0 else t50 + offsets[g]
             out[g, i] = signal_estimator(f, t, params.sig_est.npts, params.sig_est.degree, tf, dt)
     return out
+
+
+def sg_optimization(wf, params, trap_, trap_offset, npts, degree, frm, until):
+    """CPU restatement of ldsp_sg_grid_run (reference src/dsp_filter_optimization.jl:393-441).  Returns a dict with
+    amax [W, n], energy, t50_us, blmean, blslope."""
+    wf = np.asarray(wf, dtype=np.float64)
+    n, L = wf.shape
+    t0, dt = params.t_first, params.dt
+    W = len(npts)
+    out = dict(amax=np.empty((W, n)), energy=np.empty(n), t50_us=np.empty(n), blmean=np.empty(n), blslope=np.empty(n))
+    for i in range(n):
+        st = signalstats(wf[i], params.bl_from, params.bl_until, t0, dt)
+        y = invcr(wf[i] - st["mean"], params.pz_c)
+        r = intersect(y, 0.5 * y.max(), params.tx_mintot, t0, dt)
+        t50 = 0.0 if np.isnan(r["x"]) else r["x"]
+        f = trap(y, trap_.navg, trap_.ngap, trap_.navg2)
+        flen = trap_.navg + trap_.ngap + trap_.navg2
+        out["energy"][i] = signal_estimator(f, t50 + trap_offset, params.sig_est.npts, params.sig_est.degree, t0 + dt * (flen - 1), dt)
+        out["t50_us"][i] = t50 / 1000.0
+        out["blmean"][i], out["blslope"][i] = st["mean"], st["slope"]
+        for g in range(W):
+            gsg = fir(y, sg_coeffs(int(npts[g]), degree, 1))
+            out["amax"][g, i] = get_wvf_maximum(gsg, int(frm[g]), int(until[g]))
+    return out

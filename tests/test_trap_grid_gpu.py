@@ -75,3 +75,28 @@ def test_cusp_zac_grid_scans_match_oracle(orc, kind):
     ora1 = orc.fir_grid(wvfs.signal.cpu().numpy(), p1, taps1, [length / 2] * len(sel))
     np.testing.assert_allclose(full[sel], ora1, rtol=3e-5, atol=0.1)
     assert np.all(full > 100.0)   # energies of the pulses
+
+
+def test_sg_optimization_matches_oracle(orc):
+    """dsp_sg_optimization: A/E over the Savitzky-Golay window-length grid, energy, t50, baseline statistics."""
+    import dataclasses
+    # (the fixture's grid starts at 30 ns = 3 points, fewer than a cubic needs: start at 80 ns = 5 points)
+    cfg = dataclasses.replace(ldsp.reference_test_icpc_config(), a_grid_wl_sg=ldsp.StepRange(80 * ldsp.ns, 32 * ldsp.ns, 350 * ldsp.ns))
+    n = 24
+    wvfs = ldsp.ArrayOfRDWaveforms(ldsp.synth.hpge_batch(n, L, device="cuda", seed=51), 0.0, 16.0)
+    pf = {"trap": {"rt": 8 * ldsp.us, "ft": 3 * ldsp.us}}
+    res = ldsp.dsp_sg_optimization(wvfs, cfg, 500 * ldsp.us, pf)
+    grid = list(cfg.a_grid_wl_sg)
+    assert res["aoe"].shape == (len(grid), n) and bool((res["qc_label"] == -1).all())
+    p = ldsp.lower_trap_grid(cfg, 500 * ldsp.us, L, 0.0, 16.0, 1)
+    npts = [ldsp.config.sg_npoints(wl, 16.0) for wl in grid]
+    frm = [ldsp.config.window_index(cfg.current_window.left, (m - 1) * 16.0, 16.0) for m in npts]
+    until = [ldsp.config.window_index(cfg.current_window.right, (m - 1) * 16.0, 16.0) for m in npts]
+    tr = ldsp.config.trap_samples(8 * ldsp.us, 3 * ldsp.us, 16.0)
+    ora = orc.sg_optimization(wvfs.signal.cpu().numpy(), p, tr, 8 * ldsp.us + 1.5 * ldsp.us, npts, int(cfg.sg_flt_degree), frm, until)
+    np.testing.assert_allclose(res["energy"].cpu().numpy(), ora["energy"], rtol=2e-5, atol=0.05)
+    np.testing.assert_allclose(res["t50"].cpu().numpy(), ora["t50_us"], atol=5e-4)
+    np.testing.assert_allclose(res["blmean"].cpu().numpy(), ora["blmean"], atol=2e-3)
+    np.testing.assert_allclose(res["blslope"].cpu().numpy(), ora["blslope"], atol=1e-8, rtol=1e-3)
+    aoe = ora["amax"] / ora["energy"][None, :]
+    np.testing.assert_allclose(res["aoe"].cpu().numpy(), aoe, rtol=3e-4, atol=1e-6)
