@@ -269,7 +269,8 @@ int ldsp_fir_grid_run(ldsp_ctx* ctx, const float* wf, int64_t n, const ldsp_trap
  * interpolated maximum (get_wvf_maximum) of the Savitzky-Golay derivative inside the current window.
  * p->pick_mode must be 1; trap_offset = rt + ft/2 (time units).  npts[W], from[W], until[W]: SG points and the
  * current window on each filter's own output axis (0-based samples).  Outputs (device, any may be NULL):
- * amax [W][n], energy / t50_us / blmean / blslope [n]; A/E = amax / energy is the caller's division. */
+ * amax [W][n], energy / t50_us / blmean / blslope [n]; A/E = amax / energy is the caller's division.
+ * W = 0 gives dsp_qc_flt_optimization without a classifier (:31-63): energy, blmean, blslope, t50. */
 int ldsp_sg_grid_run(ldsp_ctx* ctx, const float* wf, int64_t n, const ldsp_trapgrid_params* p, const ldsp_trap* trap,
                      double trap_offset, double unit_per_us, int32_t W, const int32_t* npts, int32_t degree, const int32_t* from,
                      const int32_t* until, float* amax, float* energy, float* t50_us, float* blmean, float* blslope);

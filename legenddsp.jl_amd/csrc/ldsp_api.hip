@@ -486,11 +486,11 @@ int ldsp_fir_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgr
 int ldsp_sg_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgrid_params* p, const ldsp_trap* trap, double trap_offset,
                      double unit_per_us, int32_t W, const int32_t* npts, int32_t degree, const int32_t* from, const int32_t* until, float* amax,
                      float* energy, float* t50_us, float* blmean, float* blslope) {
-  if (!c || !p || !trap || !npts || !from || !until) return fail(LDSP_ERR_INVALID_ARG, "ldsp_sg_grid_run: NULL argument");
+  if (!c || !p || !trap || (W > 0 && (!npts || !from || !until))) return fail(LDSP_ERR_INVALID_ARG, "ldsp_sg_grid_run: NULL argument");
   int rc = ldsp_check_batch(c, wf, n, p->L, "ldsp_sg_grid_run");
   if (rc || n == 0) return rc;
   const int L = p->L;
-  if (W < 1 || W > 32) return fail(LDSP_ERR_UNSUPPORTED, "grid of %d window lengths (1..32 supported)", W);
+  if (W < 0 || W > 32) return fail(LDSP_ERR_UNSUPPORTED, "grid of %d window lengths (0..32 supported)", W);
   if (!(p->dt > 0) || !(unit_per_us > 0)) return fail(LDSP_ERR_INVALID_ARG, "dt and unit_per_us must be positive");
   if (p->pick_mode != 1 || p->tx_mintot < 1) return fail(LDSP_ERR_INVALID_ARG, "ldsp_sg_grid_run picks off at t50: pick_mode 1, tx_mintot >= 1");
   if (!check_window(p->bl_from, p->bl_until, L)) return fail(LDSP_ERR_WINDOW, "bl_window [%d,%d] outside trace", p->bl_from, p->bl_until);

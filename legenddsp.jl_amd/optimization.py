@@ -180,3 +180,42 @@ def dsp_sg_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float,
     res["energy"], res["blmean"], res["blslope"], res["t50"] = energy, blmean, blslope, t50
     res["qc_label"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
     return res
+
+
+def dsp_qc_flt_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, f_evaluate_qc=None, ctx=None) -> Table:
+    """`dsp_qc_flt_optimization(wvfs, config, tau, missing)` (reference :9-63): energy with the default trapezoid,
+    baseline mean / slope, t50 (us), qc_label = -1 (no classifier).  One launch of `ldsp_sg_grid_run` with an empty grid."""
+    if f_evaluate_qc is not None:
+        raise NotImplementedError("the SVM QC classifier is out of scope (DESIGN.md section 6)")
+    x = wvfs.signal
+    if not x.is_cuda:
+        raise _lib.LdspError(-103, "dsp_qc_flt_optimization needs device-resident waveforms (no CPU fallback)")
+    ctx = ctx or _lib.default_context(x.device.index)
+    x = _as_device_f32(x, x.device)
+    n, L = x.shape
+    rt, ft = get_fltpars({}, "trap", config)      # config.default_flt_param.trap
+    p = lower_trap_grid(config, tau, L, wvfs.t_first, wvfs.dt, 1)
+    dev = x.device
+    energy, t50, blmean, blslope = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
+    trap = trap_samples(rt, ft, wvfs.dt)
+    ctx.bind_stream()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(_lib.lib().ldsp_sg_grid_run(ctx.handle, vp(x), n, C.byref(p), C.byref(trap), float(rt) + float(ft) / 2, UNIT_PER_US, 0,
+                                           None, int(config.sg_flt_degree), None, None, None, vp(energy), vp(t50), vp(blmean), vp(blslope)))
+    res = Table()
+    res["energy"], res["blmean"], res["blslope"], res["t50"] = energy, blmean, blslope, t50
+    res["qc_label"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    return res
+
+
+def dsp_qdrift_flt_optimization(wvfs: ArrayOfRDWaveforms, blmean: torch.Tensor, config: DSPConfig, tau: float) -> torch.Tensor:
+    """`dsp_qdrift_flt_optimization(wvfs, blmean, config, tau)` (reference :72-90), spelled with the functor entry points:
+    shift by the given baseline, InvCRFilter, get_t0, get_qdrift."""
+    from .filters import InvCRFilter, shift_waveform
+    from .routines import get_qdrift, get_t0
+    kw = config.kwargs_pars
+    w = shift_waveform(wvfs, -blmean)
+    w = InvCRFilter(tau)(w)
+    t0 = get_t0(w, config.t0_threshold, flt_pars=tuple(kw.t0_flt_pars), mintot=kw.t0_mintot)
+    return get_qdrift(w, t0, (config.qdrift_int_length.first, config.qdrift_int_length.last),
+                      pol_power=int(kw.int_interpolation_order), sign_est_length=kw.int_interpolation_length)

@@ -100,3 +100,24 @@ def test_sg_optimization_matches_oracle(orc):
     np.testing.assert_allclose(res["blslope"].cpu().numpy(), ora["blslope"], atol=1e-8, rtol=1e-3)
     aoe = ora["amax"] / ora["energy"][None, :]
     np.testing.assert_allclose(res["aoe"].cpu().numpy(), aoe, rtol=3e-4, atol=1e-6)
+
+
+def test_qc_and_qdrift_flt_optimization_agree_with_the_fused_chain():
+    """dsp_qc_flt_optimization (no classifier) and dsp_qdrift_flt_optimization reproduce what the fused dsp_icpc kernel
+    computes for the same definitions: blmean / blslope / t50 and the qdrift column."""
+    cfg = ldsp.reference_test_icpc_config()
+    n = 64
+    sig = ldsp.synth.hpge_batch(n, L, device="cuda", seed=61)
+    wvfs = ldsp.ArrayOfRDWaveforms(sig, 0.0, 16.0)
+    p = ldsp.lower_icpc(cfg, 500 * ldsp.us, {}, L, 0.0, 16.0)
+    full = {k: v for k, v in ldsp.table_columns(ldsp.icpc_run(sig, p)).items()}
+    qc = ldsp.dsp_qc_flt_optimization(wvfs, cfg, 500 * ldsp.us)
+    torch.testing.assert_close(qc["blmean"], full["blmean"], rtol=0, atol=0)          # same summation, same pivot
+    torch.testing.assert_close(qc["blslope"], full["blslope"], rtol=1e-6, atol=1e-12)
+    # t50 here crosses half the maximum of the pole-zero corrected trace (:46), dsp_icpc half the raw maximum minus
+    # baseline (dsp_icpc.jl:111,133): a few ns apart, and the flat-top energy follows within 1e-3
+    torch.testing.assert_close(qc["t50"], full["t50"], rtol=0, atol=0.05)
+    torch.testing.assert_close(qc["energy"], full["e_trap"], rtol=1e-3, atol=0.5)      # default trapezoid = trap_opt without pars_filter
+    assert bool((qc["qc_label"] == -1).all())
+    qd = ldsp.dsp_qdrift_flt_optimization(wvfs, full["blmean"], cfg, 500 * ldsp.us)
+    torch.testing.assert_close(qd, full["qdrift"], rtol=2e-4, atol=30.0)               # unfused spelling: float32 cumsums over 8192 samples
