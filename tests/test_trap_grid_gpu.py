@@ -121,3 +121,27 @@ def test_qc_and_qdrift_flt_optimization_agree_with_the_fused_chain():
     assert bool((qc["qc_label"] == -1).all())
     qd = ldsp.dsp_qdrift_flt_optimization(wvfs, full["blmean"], cfg, 500 * ldsp.us)
     torch.testing.assert_close(qd, full["qdrift"], rtol=2e-4, atol=30.0)               # unfused spelling: float32 cumsums over 8192 samples
+
+
+def test_thin_routines_dsp_decay_times_and_dsp_puls(orc):
+    """recombinations of the path's stages through the functor entry points."""
+    cfg = ldsp.reference_test_icpc_config()
+    n = 32
+    sig = ldsp.synth.hpge_batch(n, L, device="cuda", seed=71)
+    wvfs = ldsp.ArrayOfRDWaveforms(sig, 0.0, 16.0)
+    p = ldsp.lower_icpc(cfg, 500 * ldsp.us, {}, L, 0.0, 16.0)
+    full = ldsp.table_columns(ldsp.icpc_run(sig, p))
+    tau = ldsp.dsp_decay_times(wvfs, cfg)
+    torch.testing.assert_close(tau, full["tail_tau"] / 1000.0, rtol=2e-5, atol=1e-3)      # us; the fused kernel reports time-axis units
+    data = ldsp.Table(waveform=wvfs, baseline=torch.zeros(n), timestamp=torch.arange(n), eventnumber=torch.arange(1, n + 1), daqenergy=torch.zeros(n))
+    r = ldsp.dsp_puls(data, cfg)
+    for c in ("blmean", "blsigma", "blslope", "bloffset"):
+        torch.testing.assert_close(r[c], full[c], rtol=2e-5, atol=2e-3 if c != "blslope" else 1e-8)
+    x = sig.cpu().numpy().astype(np.float64)
+    xs = x - full["blmean"].cpu().numpy()[:, None].astype(np.float64)
+    np.testing.assert_allclose(r["e_max"].cpu().numpy(), xs.max(axis=1), rtol=1e-6, atol=2e-3)
+    e_ref = np.array([orc.trap(xs[i], 625, 250).max() for i in range(n)])
+    np.testing.assert_allclose(r["e_10410"].cpu().numpy(), e_ref, rtol=2e-5, atol=0.05)
+    t_ref = np.array([orc.intersect(xs[i], 0.5 * xs[i].max(), ldsp.config.nsamples(1000.0, 16.0), 0.0, 16.0)["x"] for i in range(n)]) / 1000.0
+    np.testing.assert_allclose(r["t50"].cpu().numpy(), np.nan_to_num(t_ref), atol=5e-4)
+    assert torch.equal(r["eventID_fadc"], torch.arange(1, n + 1))
