@@ -193,12 +193,12 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
 
 #include "sipm_s4.inc"
 
-template <int NT, int R>
+template <int NT, int R, bool FULL>
 static hipError_t launch_s4(const float* wf, int64_t n, const SipmDev& d, const SipmOutDev& od, hipStream_t st) {
   const size_t bytes = S4Lds<NT, R>::bytes();
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sipm_s4<NT, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sipm_s4<NT, R, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_sipm_s4<NT, R>), dim3((unsigned)n), dim3(NT), bytes, st, wf, d, od);
+  hipLaunchKernelGGL((k_sipm_s4<NT, R, FULL>), dim3((unsigned)n), dim3(NT), bytes, st, wf, d, od);
   return hipGetLastError();
 }
 
@@ -247,14 +247,15 @@ extern "C" int ldsp_sipm_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp
   hipError_t e = hipErrorInvalidValue;
   bool launched = false;
   if (s4_ok) {
+    // smallest tile that holds the trace: 32 samples per thread, 64 .. 512 threads
+#define LDSP_S4(N) (L == 32 * N ? sipm::launch_s4<N, 8, true>(wf, n, d, od, c->stream) : sipm::launch_s4<N, 8, false>(wf, n, d, od, c->stream))
     launched = true;
-    switch (L) {
-      case 16384: e = sipm::launch_s4<512, 8>(wf, n, d, od, c->stream); break;
-      case 8192: e = sipm::launch_s4<256, 8>(wf, n, d, od, c->stream); break;
-      case 4096: e = sipm::launch_s4<128, 8>(wf, n, d, od, c->stream); break;
-      case 2048: e = sipm::launch_s4<64, 8>(wf, n, d, od, c->stream); break;
-      default: launched = false;
-    }
+    if (L <= 2048) e = LDSP_S4(64);
+    else if (L <= 4096) e = LDSP_S4(128);
+    else if (L <= 8192) e = LDSP_S4(256);
+    else if (L <= 16384) e = LDSP_S4(512);
+    else launched = false;
+#undef LDSP_S4
   }
   if (!launched) {
     const size_t p4 = (size_t)(((L + 3) & ~3) + 64);

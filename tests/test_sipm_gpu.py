@@ -68,8 +68,10 @@ def test_sipm_reference_fixture_properties():
     assert len(res.trig_pos) == 10
 
 
-def test_sipm_matches_oracle_odd_length(orc):
-    n, L = 32, 6250
+@pytest.mark.parametrize("L", [6250, 5000, 3500, 12001])
+def test_sipm_matches_oracle_odd_length(orc, L):
+    """Traces that do not fill the register kernel's tile (rows 16-byte aligned or not)."""
+    n = 32
     p = ldsp.lower_sipm(ldsp.reference_test_sipm_config(), {"sg": {"wl": 200 * ldsp.ns}}, L, 0.0, 16.0)
     wf = ldsp.synth.sipm_batch(n, L, device="cuda", seed=9)
     sc, trig = ldsp.sipm_run(wf, p)
