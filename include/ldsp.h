@@ -315,6 +315,16 @@ int ldsp_rdfilt_moving_window_multi(ldsp_ctx*, const float* x, int64_t n, int32_
 int ldsp_rdfilt_affine(ldsp_ctx*, const float* x, int64_t n, int32_t L, int32_t from, int32_t until,
                        double scale, double shift, const float* shift_per_trace, int32_t reverse, float* y);
 
+/* QC classifier front end: get_qc_classifier / get_qc_classifier_compressed (src/dsp_ml_routines.jl:9-24, 45-60;
+ * with a DSPConfig :26-34, :62-70): optional signalstats(bl).mean + shift_waveform, HaarAveragingFilter(2) applied
+ * `levels` times (5, compressed: 2), division by max(|min|, |max|) (0 -> 1).  features: device [n][Lout],
+ * Lout = ldsp_qc_features_len(L, levels) — the memory of flatview(VectorOfSimilarArrays(signal)) that the
+ * reference hands to f_evaluate_qc (src/ml.jl:6-22: LIBSVM svmpredict).  bl_from < 0: no baseline subtraction
+ * (the trace is already shifted, src/dsp_icpc.jl:105-108).  norm: optional device [n], the divisor. */
+int32_t ldsp_qc_features_len(int32_t L, int32_t levels);
+int ldsp_qc_features(ldsp_ctx*, const float* x, int64_t n, int32_t L, int32_t levels, int32_t bl_from, int32_t bl_until,
+                     float* features, float* norm);
+
 /* Host-side coefficient builders (double, length = p->length or npts). */
 int ldsp_cusp_coeffs(const ldsp_cuspzac* p, double* h);
 int ldsp_zac_coeffs(const ldsp_cuspzac* p, double* h);

@@ -89,6 +89,8 @@ def _declare(lib):
         "ldsp_intersect_maximum": [_VOIDP, _VOIDP, _I64, _I32, _DBL, _DBL, _VOIDP, _I32, _I32, C.POINTER(_abi.TrigOut)],
         "ldsp_multi_intersect": [_VOIDP, _VOIDP, _I64, _I32, _DBL, _DBL, _VOIDP, _I32, _I32, _I32, _I32, _I32, _VOIDP, _VOIDP],
         "ldsp_signal_estimator": [_VOIDP, _VOIDP, _I64, _I32, _DBL, _DBL, _VOIDP, _abi.Dni, _VOIDP],
+        "ldsp_qc_features": [_VOIDP, _VOIDP, _I64, _I32, _I32, _I32, _I32, _VOIDP, _VOIDP],
+        "ldsp_qc_features_len": [_I32, _I32],
     }
     for name, argtypes in opt.items():
         if hasattr(lib, name):
@@ -106,7 +108,7 @@ DECLARED_SYMBOLS = [
     "ldsp_rdfilt_moving_window_multi", "ldsp_rdfilt_affine", "ldsp_cusp_coeffs", "ldsp_zac_coeffs",
     "ldsp_sg_coeffs", "ldsp_signalstats", "ldsp_tailstats", "ldsp_extremestats", "ldsp_thresholdstats",
     "ldsp_thresholdstats_mad", "ldsp_saturation", "ldsp_get_wvf_maximum", "ldsp_intersect",
-    "ldsp_intersect_maximum", "ldsp_multi_intersect", "ldsp_signal_estimator",
+    "ldsp_intersect_maximum", "ldsp_multi_intersect", "ldsp_signal_estimator", "ldsp_qc_features", "ldsp_qc_features_len",
 ]
 
 

@@ -186,6 +186,61 @@ __global__ void __launch_bounds__(256) k_elem(const float* __restrict__ x, int L
   }
 }
 
+// ---------------------------------------------------------------- QC classifier front end
+// get_qc_classifier / get_qc_classifier_compressed (src/dsp_ml_routines.jl:9-24, 45-60): [signalstats(bl).mean and
+// shift_waveform(-mean) when a baseline window is given (:26-34, :62-70)] -> HaarAveragingFilter(2) `levels` times
+// (5 / 2) -> divide by max(|min|, |max|) of the result (0 -> 1) -> one row of the feature matrix handed to the SVM.
+// One workgroup per trace; level 1 reads the trace from global memory, the further levels ping-pong in LDS.
+__global__ void __launch_bounds__(256) k_qc_features(const float* __restrict__ x, int L, int levels, int bl_from, int bl_until,
+                                                     float* __restrict__ feat, float* __restrict__ norm_out) {
+  extern __shared__ __align__(16) unsigned char raw[];
+  __shared__ double red[8];
+  __shared__ float fred[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = x + (size_t)blockIdx.x * L;
+  const int n1 = (L + 1) >> 1;
+  float* A = reinterpret_cast<float*>(raw);   // [ceil(L/2)]
+  float* B = A + ((n1 + 3) & ~3);             // [ceil(L/4)]
+  float mean = 0.f;
+  if (bl_from >= 0) {   // mean about the window's first sample, wave partials combined in double (as the fused kernels)
+    const float pv = xr[bl_from];
+    float s = 0.f;
+    for (int i = bl_from + tid; i <= bl_until; i += 256) s += xr[i] - pv;
+    s = wave_sum_all(s);
+    if (lane == 0) red[wave] = (double)s;
+    __syncthreads();
+    mean = (float)((double)pv + (red[0] + red[1] + red[2] + red[3]) / (double)(bl_until - bl_from + 1));
+  }
+  const float c = 0.70710678118654752f;   // inv(sqrt(T(2)))  src/haar_filter.jl:27
+  for (int i = tid; i < n1; i += 256) {
+    const int s = 2 * i;
+    A[i] = ((xr[s] - mean) + (xr[min(s + 1, L - 1)] - mean)) * c;
+  }
+  __syncthreads();
+  float *src = A, *dst = B;
+  int n = n1;
+  for (int lv = 1; lv < levels; ++lv) {
+    const int no = (n + 1) >> 1;
+    for (int i = tid; i < no; i += 256) dst[i] = (src[2 * i] + src[min(2 * i + 1, n - 1)]) * c;
+    __syncthreads();
+    float* t = src; src = dst; dst = t;
+    n = no;
+  }
+  float mx = -INFINITY, mn = INFINITY;
+  for (int i = tid; i < n; i += 256) { mx = fmaxf(mx, src[i]); mn = fminf(mn, src[i]); }
+  mx = wave_max_all(mx); mn = wave_min_all(mn);
+  if (lane == 0) { fred[wave] = mx; fred[4 + wave] = mn; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(fred[0], fred[1]), fmaxf(fred[2], fred[3]));
+  mn = fminf(fminf(fred[4], fred[5]), fminf(fred[6], fred[7]));
+  float nf = fmaxf(fabsf(mn), fabsf(mx));   // max(abs(first(extrema)), abs(last(extrema)))  :17
+  if (nf == 0.f) nf = 1.f;                  // replace!(norm_fact, 0.0 => 1)  :18
+  const float inv = 1.f / nf;               // multiply_waveform.(w, 1 ./ norm_fact)  :20
+  float* fr = feat + (size_t)blockIdx.x * n;
+  for (int i = tid; i < n; i += 256) fr[i] = src[i] * inv;
+  if (norm_out && tid == 0) norm_out[blockIdx.x] = nf;
+}
+
 // ---------------------------------------------------------------- extractors
 // MODE 0 signalstats, 1 tailstats, 2 extremestats, 3 get_wvf_maximum, 4 thresholdstats,
 //      5 thresholdstats_mad, 6 saturation
@@ -660,6 +715,27 @@ int ldsp_signal_estimator(ldsp_ctx* c, const float* x, int64_t n, int32_t L, dou
   if ((rc = upload_coef(c, tab))) return rc;
   hipLaunchKernelGGL(k_signal_estimator, dim3((unsigned)n), dim3(64), 0, c->stream, x, L, (float)t_first, (float)dt, t,
                      (const float*)c->d_coef, est.npts, est.degree, out);
+  LAUNCH_CHECK();
+  return LDSP_OK;
+}
+
+int32_t ldsp_qc_features_len(int32_t L, int32_t levels) {
+  int32_t n = L;
+  for (int i = 0; i < levels; ++i) n = (n + 1) / 2;
+  return n;
+}
+int ldsp_qc_features(ldsp_ctx* c, const float* x, int64_t n, int32_t L, int32_t levels, int32_t bl_from, int32_t bl_until,
+                     float* features, float* norm) {
+  int rc = ldsp_check_batch(c, x, n, L, "ldsp_qc_features");
+  if (rc || n == 0) return rc;
+  if (!features) return ldsp_fail(LDSP_ERR_INVALID_ARG, "output pointer is NULL");
+  if (levels < 1 || levels > 16) return ldsp_fail(LDSP_ERR_INVALID_ARG, "Haar levels %d outside 1..16", levels);
+  if (bl_from >= 0 && !win_ok(bl_from, bl_until, L)) return ldsp_fail(LDSP_ERR_WINDOW, "baseline window [%d,%d] outside the trace", bl_from, bl_until);
+  const int n1 = (L + 1) / 2, n2 = (n1 + 1) / 2;
+  const size_t b = ((size_t)((n1 + 3) & ~3) + (size_t)((n2 + 3) & ~3)) * 4;
+  if (b > 150 * 1024) return ldsp_fail(LDSP_ERR_UNSUPPORTED, "trace of %d samples does not fit the Haar stage's LDS", L);
+  if ((rc = set_lds(k_qc_features, b))) return rc;
+  hipLaunchKernelGGL(k_qc_features, dim3((unsigned)n), dim3(256), b, c->stream, x, L, levels, bl_from, bl_until, features, norm);
   LAUNCH_CHECK();
   return LDSP_OK;
 }

@@ -146,8 +146,6 @@ def dsp_zac_ft_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: fl
 def dsp_sg_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, pars_filter: dict, f_evaluate_qc=None, ctx=None) -> Table:
     """`dsp_sg_optimization(wvfs, config, tau, pars_filter)` (reference :393-441): A/E over the Savitzky-Golay window
     lengths `config.a_grid_wl_sg`.  Columns: aoe [W, n], energy, blmean, blslope, t50 (us), qc_label (-1: no classifier)."""
-    if f_evaluate_qc is not None:
-        raise NotImplementedError("the SVM QC classifier is out of scope (DESIGN.md section 6)")
     x = wvfs.signal
     if not x.is_cuda:
         raise _lib.LdspError(-103, "dsp_sg_optimization needs device-resident waveforms (no CPU fallback)")
@@ -178,15 +176,17 @@ def dsp_sg_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float,
     res = Table()
     res["aoe"] = amax / energy[None, :]
     res["energy"], res["blmean"], res["blslope"], res["t50"] = energy, blmean, blslope, t50
-    res["qc_label"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    if f_evaluate_qc is None:
+        res["qc_label"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    else:   # get_qc_classifier on the baseline-subtracted traces (reference :408-411)
+        from .ml_routines import get_qc_classifier
+        res["qc_label"] = torch.as_tensor(get_qc_classifier(wvfs, f_evaluate_qc, config, ctx)).to(torch.int32)
     return res
 
 
 def dsp_qc_flt_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, f_evaluate_qc=None, ctx=None) -> Table:
     """`dsp_qc_flt_optimization(wvfs, config, tau, missing)` (reference :9-63): energy with the default trapezoid,
-    baseline mean / slope, t50 (us), qc_label = -1 (no classifier).  One launch of `ldsp_sg_grid_run` with an empty grid."""
-    if f_evaluate_qc is not None:
-        raise NotImplementedError("the SVM QC classifier is out of scope (DESIGN.md section 6)")
+    baseline mean / slope, t50 (us), qc_label (-1 without a classifier).  One launch of `ldsp_sg_grid_run` with an empty grid."""
     x = wvfs.signal
     if not x.is_cuda:
         raise _lib.LdspError(-103, "dsp_qc_flt_optimization needs device-resident waveforms (no CPU fallback)")
@@ -204,7 +204,13 @@ def dsp_qc_flt_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: fl
                                            None, int(config.sg_flt_degree), None, None, None, vp(energy), vp(t50), vp(blmean), vp(blslope)))
     res = Table()
     res["energy"], res["blmean"], res["blslope"], res["t50"] = energy, blmean, blslope, t50
-    res["qc_label"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    if f_evaluate_qc is None:
+        res["qc_label"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    else:   # get_qc_classifier on the pole-zero corrected traces (reference :31-49)
+        from .filters import InvCRFilter, shift_waveform
+        from .ml_routines import get_qc_classifier
+        w_pz = InvCRFilter(float(tau))(shift_waveform(ArrayOfRDWaveforms(x, wvfs.t_first, wvfs.dt), -blmean))
+        res["qc_label"] = torch.as_tensor(get_qc_classifier(w_pz, f_evaluate_qc, None, ctx)).to(torch.int32)
     return res
 
 

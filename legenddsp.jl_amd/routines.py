@@ -112,9 +112,6 @@ def dsp_icpc(data: Table, config: DSPConfig, tau: float, pars_filter: dict, f_ev
              ctx: _lib.Context = None) -> Table:
     """`dsp_icpc(data::Table, config::DSPConfig, τ, pars_filter::PropDict)` — reference
     src/dsp_icpc.jl:62.  `data.waveform` is an ArrayOfRDWaveforms; returns the 53-column Table."""
-    if f_evaluate_qc is not None:
-        raise NotImplementedError("QC classifier (reference src/dsp_ml_routines.jl) is outside the hot path; "
-                                  "qc_label is -1 as with f_evaluate_qc = missing (dsp_icpc.jl:108)")
     wvfs: ArrayOfRDWaveforms = data["waveform"]
     n = len(wvfs)
     params = lower_icpc(config, tau, pars_filter, wvfs.nsamples, wvfs.t_first, wvfs.dt)
@@ -125,7 +122,11 @@ def dsp_icpc(data: Table, config: DSPConfig, tau: float, pars_filter: dict, f_ev
     order = ["blmean", "blsigma", "blslope", "bloffset", "tailmean", "tailsigma", "tailslope", "tailoffset"]
     for k in order:
         res[k] = c[k]
-    res["qc_label"] = torch.full((n,), -1, dtype=torch.int64, device=dev)  # dsp_icpc.jl:108
+    if f_evaluate_qc is None:
+        res["qc_label"] = torch.full((n,), -1, dtype=torch.int64, device=dev)  # dsp_icpc.jl:108 (f_evaluate_qc = missing)
+    else:   # Int.(get_qc_classifier(wvfs - blmean, f_evaluate_qc))   dsp_icpc.jl:105-108
+        from .ml_routines import get_qc_classifier
+        res["qc_label"] = torch.as_tensor(get_qc_classifier(wvfs, f_evaluate_qc, config, ctx)).to(torch.int64)
     for k in ["t0", "t10", "t50", "t80", "t90", "t99", "t50_current", "drift_time"]:
         res[k] = c[k]
     res["tail_τ"] = c["tail_tau"]

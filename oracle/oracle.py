@@ -299,3 +299,21 @@ def sg_optimization(wf, params, trap_, trap_offset, npts, degree, frm, until):
             gsg = fir(y, sg_coeffs(int(npts[g]), degree, 1))
             out["amax"][g, i] = get_wvf_maximum(gsg, int(frm[g]), int(until[g]))
     return out
+
+
+def qc_features(wf, levels, bl_from=-1, bl_until=-1):
+    """get_qc_classifier front end (reference src/dsp_ml_routines.jl:9-34, 45-70) in float64: optional
+    signalstats(bl).mean + shift, HaarAveragingFilter(2) `levels` times, division by max(|min|, |max|) (0 -> 1).
+    Returns (features [n][Lout], norm [n])."""
+    wf = np.asarray(wf, dtype=np.float64)
+    rows, norms = [], []
+    for x in wf:
+        if bl_from >= 0:
+            x = x - signalstats(x, bl_from, bl_until)["mean"]
+        for _ in range(int(levels)):
+            x = haar(x, 2)
+        nf = max(abs(x.min()), abs(x.max()))
+        if nf == 0.0:
+            nf = 1.0
+        rows.append(x * (1.0 / nf)); norms.append(nf)
+    return np.stack(rows), np.array(norms)
