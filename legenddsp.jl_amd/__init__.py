@@ -21,6 +21,7 @@ from .optimization import (dsp_trap_rt_optimization, dsp_trap_ft_optimization, d
                            dsp_cusp_ft_optimization, dsp_zac_ft_optimization, dsp_sg_optimization, dsp_qc_flt_optimization, dsp_qdrift_flt_optimization, trap_grid_run, fir_grid_run, lower_trap_grid,
                            cuspzac_grid_taps)
 from .thin_routines import dsp_decay_times, dsp_puls
+from .compressed import dsp_icpc_compressed, slope_residual_sigma
 from .ml_routines import get_qc_classifier, get_qc_classifier_compressed, qc_features, RbfSvmPredictor
 from .extractors import (VectorOfVectors, signalstats, tailstats, extremestats, thresholdstats, thresholdstats_mad,
                          saturation, get_wvf_maximum, Intersect, IntersectMaximum, MultiIntersect, PolynomialDNI,

@@ -215,15 +215,20 @@ def _check_window(name, a, b, n):
 DEFAULT_T0_FLT_PARS = (40.0 * ns, 100.0 * ns, 2000.0 * ns)  # src/dsp_routines.jl:9
 
 
-def lower_icpc(config: DSPConfig, tau: float, pars_filter: dict, L: int, t_first: float, dt: float) -> _abi.IcpcParams:
+def lower_icpc(config: DSPConfig, tau: float, pars_filter: dict, L: int, t_first: float, dt: float,
+               presum_rate: int = None) -> _abi.IcpcParams:
     """Lower (DSPConfig, tau, pars_filter) + sampling info of the traces to ldsp_icpc_params.
 
-    Follows the parameter unpacking of reference src/dsp_icpc.jl:64-99."""
+    Follows the parameter unpacking of reference src/dsp_icpc.jl:64-99.  `presum_rate` (dsp_icpc_compressed, :293-350,
+    for the presummed traces): upper rail scaled by the rate (:339), one Savitzky-Golay window `sg_wl * rate / 2`
+    (:441) — the only SG filter that routine applies to the presummed traces."""
     kw = config.kwargs_pars
     p = _abi.IcpcParams()
     p.L, p.t_first, p.dt, p.unit_per_us = int(L), float(t_first), float(dt), UNIT_PER_US
     bit_depth = int(kw.fc_bit_depth)
     p.sat_low, p.sat_high = 0.0, float(2 ** bit_depth - bit_depth)  # dsp_icpc.jl:94
+    if presum_rate is not None:
+        p.sat_high *= float(presum_rate)                             # dsp_icpc.jl:339
     p.bl_from = window_index(config.bl_window.left, t_first, dt)
     p.bl_until = window_index(config.bl_window.right, t_first, dt)
     p.tail_from = window_index(config.tail_window.left, t_first, dt)
@@ -254,9 +259,17 @@ def lower_icpc(config: DSPConfig, tau: float, pars_filter: dict, L: int, t_first
     p.zac = cuspzac_lowered(zac_rt, zac_ft, tau_off, config.flt_length_zac, float(config.flt_length_zac) / float(dt), dt)
     p.cusp_pickoff = float(config.flt_length_cusp) / 2
     p.zac_pickoff = float(config.flt_length_zac) / 2
-    for i, wl in enumerate((sg_wl, 60 * ns, 100 * ns)):
+    sg_windows = (sg_wl, 60 * ns, 100 * ns) if presum_rate is None else (float(sg_wl) * presum_rate / 2,) * 3
+    for i, wl in enumerate(sg_windows):
         p.sg_npts[i] = sg_npoints(wl, dt)
     p.sg_degree = int(config.sg_flt_degree)
+    if presum_rate is not None:
+        # the scaled window can be shorter than degree + 1 points (50 ns at 16 ns: 3 points, degree 3 in the reference's
+        # own test, test/test_dsp_icpc.jl:164-170): the fit is then the interpolating polynomial.  Both uses of this
+        # filter (pile-up threshold in sigmas, t50_current at half maximum) do not depend on its scale.
+        p.sg_degree = min(p.sg_degree, p.sg_npts[0] - 1)
+        # qdrift / lq are taken from the windowed traces: the integral estimator only has to be well-formed here
+        p.int_est = _abi.Dni(max(p.int_est.npts, p.int_est.degree + 1), p.int_est.degree)
     p.cur_left, p.cur_right = config.current_window.left, config.current_window.right
     p.intrace_nsigma = float(config.inTraceCut_std_threshold)
     p.intrace_mintot = max(1, nsamples(kw.intrace_mintot, dt))

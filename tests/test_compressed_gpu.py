@@ -1,0 +1,126 @@
+"""dsp_icpc_compressed (reference src/dsp_icpc.jl:293-499): the reference's own smoke test
+(test/test_dsp_icpc.jl:164-200: presummed == windowed == the full trace, presum_rate 1), parity of the presummed half with
+the oracle, of the windowed half with the fused full-trace chain, and a genuinely presummed / windowed pair (rate 4)."""
+import numpy as np
+import pytest
+import torch
+
+import legenddsp_jl_amd as ldsp
+import parity
+
+pytestmark = pytest.mark.gpu
+DT = 16.0
+EXPECTED = ["blfc", "timestamp", "eventID_fadc", "e_fc", "deadtime", "n_sat_low", "n_sat_high", "n_sat_low_cons", "n_sat_high_cons",
+            "t_sat_lo", "t_sat_hi", "blmean", "blsigma", "blslope", "bloffset", "bl_slope_sigma",
+            "auxbl1_mean", "auxbl1_sigma", "auxbl1_slope_sigma", "auxbl2_mean", "auxbl2_sigma", "auxbl2_slope_sigma", "qc_label",
+            "e_max", "e_min", "e_max_pre", "e_min_pre", "tailmean", "tailsigma", "tailslope", "tailoffset", "tail_τ", "tail_mean",
+            "tail_sigma", "auxpz1_mean", "auxpz1_sigma", "auxpz1_slope_sigma", "auxpz2_mean", "auxpz2_sigma", "auxpz2_slope_sigma",
+            "t0", "t10", "t50", "t80", "t90", "t99", "t50_pre", "drift_time", "t50_current", "e_10410", "e_535", "e_313", "e_trap",
+            "e_cusp", "e_zac", "e_trap_max", "e_cusp_max", "e_zac_max", "t_trap_max", "t_cusp_max", "t_zac_max", "qdrift", "lq",
+            "a_sg", "a_60", "a_100", "a_raw", "inTrace_intersect", "inTrace_n", "e_10410_inv", "e_313_inv", "t0_inv"]   # :461-497
+
+
+def _data(pre, wdw, rate, n):
+    z = torch.zeros(n)
+    return ldsp.Table(waveform_presummed=pre, waveform_windowed=wdw, presum_rate=torch.full((n,), rate, dtype=torch.int32),
+                      baseline=z, timestamp=torch.arange(n), eventnumber=torch.arange(1, n + 1), daqenergy=z,
+                      t_sat_lo=z, t_sat_hi=z, deadtime=z)
+
+
+def _np(t):
+    return t.cpu().numpy().astype(np.float64)
+
+
+def test_reference_smoke_case():
+    """test/test_dsp_icpc.jl:164-200 — the noiseless fixture as both columns, rate 1."""
+    cfg = ldsp.reference_test_icpc_config()
+    wf = ldsp.synth.reference_hpge_waveform().float()[None].repeat(3, 1).cuda()
+    w = ldsp.ArrayOfRDWaveforms(wf, 0.0, DT)
+    res = ldsp.dsp_icpc_compressed(_data(w, w, 1, 3), cfg, 500 * ldsp.us, {})
+    assert res.columnnames == EXPECTED and len(res) == 3
+    assert bool((res.t0 < res.t50).all()) and bool((res.t50 < res.t90).all()) and bool((res.drift_time >= 0).all())
+    for c in ("e_10410", "e_313", "e_trap"):
+        assert bool(torch.isfinite(res[c]).all())
+    assert bool((res.qc_label == -1).all())
+    np.testing.assert_allclose(_np(res.blmean), 1000.0, rtol=1e-6)
+    np.testing.assert_allclose(_np(res.bl_slope_sigma), 0.0, atol=1e-3)
+    np.testing.assert_allclose(_np(res.e_max), 10000.0, rtol=1e-6)
+
+
+def test_same_trace_rate1_against_oracle_and_fused(orc):
+    n, L = 128, 8192
+    cfg = ldsp.reference_test_icpc_config()
+    tau = 500 * ldsp.us
+    wf = ldsp.synth.hpge_batch(n, L, device="cuda", seed=404)
+    w = ldsp.ArrayOfRDWaveforms(wf, 0.0, DT)
+    res = ldsp.dsp_icpc_compressed(_data(w, w, 1, n), cfg, tau, {})
+    x = wf.cpu().numpy()
+    # presummed half == the oracle's chain with the parameters of :339, :441 (3-point SG window on the presummed trace)
+    pa = ldsp.lower_icpc(cfg, tau, {}, L, 0.0, DT, presum_rate=1)
+    assert list(pa.sg_npts) == [3, 3, 3] and pa.sg_degree == 2
+    ora = orc.dsp_icpc(x, pa, nthreads=16)
+    ren = {"e_max": "e_max_pre", "e_min": "e_min_pre", "t50": "t50_pre", "tail_tau": "tail_τ"}
+    pre_cols = ["n_sat_low", "n_sat_high", "blmean", "blsigma", "blslope", "bloffset", "e_max", "e_min", "tailmean", "tailsigma", "tailslope",
+                "tailoffset", "tail_tau", "tail_mean", "tail_sigma", "t50", "t50_current", "e_10410", "e_535", "e_313", "e_trap", "e_cusp",
+                "e_zac", "e_trap_max", "e_cusp_max", "e_zac_max", "inTrace_intersect", "inTrace_n", "e_10410_inv", "e_313_inv"]
+    for c in pre_cols:
+        a, b = _np(res[ren.get(c, c)]), ora[c]
+        tol = 5e-4 if c in parity.TIME_US else parity.ATOL.get(c, 0.0) + parity.RTOL * np.abs(b)
+        bad = ~(np.abs(a - b) <= tol) & ~(np.isnan(a) & np.isnan(b))
+        assert bad.sum() <= max(1, n // 100), (c, a[bad][:4], b[bad][:4])
+    # windowed half == the fused full-trace chain on the same trace (itself oracle-checked in test_icpc_gpu.py)
+    fused = ldsp.table_columns(ldsp.icpc_run(wf, ldsp.lower_icpc(cfg, tau, {}, L, 0.0, DT)))
+    for c in ("e_max", "e_min"):
+        np.testing.assert_allclose(_np(res[c]), _np(fused[c]), rtol=1e-6, atol=2e-3)
+    for c in ("t0", "t10", "t50", "t80", "t90", "t99", "t0_inv"):
+        np.testing.assert_allclose(_np(res[c]), _np(fused[c]), atol=1e-3, err_msg=c)
+    np.testing.assert_allclose(_np(res.drift_time), _np(fused["drift_time"]), atol=1.5)
+    for c in ("qdrift", "lq"):
+        np.testing.assert_allclose(_np(res[c]), _np(fused[c]), rtol=3e-4, atol=60, err_msg=c)
+    for c in ("a_sg", "a_60", "a_100", "a_raw"):
+        a, b = _np(res[c]), _np(fused[c])
+        assert (np.abs(a - b) > 1e-2 + 1e-4 * np.abs(b)).sum() <= 2, c      # near-ties of the arg-max move the parabola
+    # auxiliary windows: signalstats of the oracle; A8's identity against an explicit line fit
+    for name, win, shifted in (("auxbl1", cfg.auxbl1_window, False), ("auxbl2", cfg.auxbl2_window, False),
+                               ("auxpz1", cfg.auxpz1_window, True), ("auxpz2", cfg.auxpz2_window, True)):
+        a, b = ldsp.config.window_index(win.left, 0.0, DT), ldsp.config.window_index(win.right, 0.0, DT)
+        for i in range(0, n, 16):
+            o = orc.signalstats(x[i], a, b, 0.0, DT)
+            off = ora["blmean"][i] if shifted else 0.0
+            assert float(res[f"{name}_mean"][i]) == pytest.approx(o["mean"] - off, abs=5e-3)
+            assert float(res[f"{name}_sigma"][i]) == pytest.approx(o["sigma"], rel=1e-4, abs=1e-4)
+            t = DT * np.arange(a, b + 1)
+            yy = x[i, a:b + 1].astype(np.float64)
+            resid = yy - np.polyval(np.polyfit(t - t.mean(), yy, 1), t - t.mean())
+            assert float(res[f"{name}_slope_sigma"][i]) == pytest.approx(resid.std(), rel=1e-3, abs=1e-3)
+
+
+def test_presummed_and_windowed_pair_rate4(orc):
+    """A genuine pair: presummed = sums of 4 samples (64 ns), windowed = 2048 full-rate samples around the rise."""
+    n, L, rate = 96, 8192, 4
+    cfg = ldsp.reference_test_icpc_config()
+    tau = 500 * ldsp.us
+    wf = ldsp.synth.hpge_batch(n, L, device="cuda", seed=11)
+    pre = ldsp.ArrayOfRDWaveforms(wf.view(n, L // rate, rate).sum(dim=2).contiguous(), 0.0, DT * rate)
+    w0 = 2000
+    wdw = ldsp.ArrayOfRDWaveforms(wf[:, w0:w0 + 3000].contiguous(), w0 * DT, DT)
+    res = ldsp.dsp_icpc_compressed(_data(pre, wdw, rate, n), cfg, tau, {})
+    assert res.columnnames == EXPECTED
+    # presummed half against the oracle at its own sampling step
+    pa = ldsp.lower_icpc(cfg, tau, {}, L // rate, 0.0, DT * rate, presum_rate=rate)
+    assert pa.sat_high == 4 * 65520.0
+    ora = orc.dsp_icpc(pre.signal.cpu().numpy(), pa, nthreads=16)
+    for c, rc in (("blmean", "blmean"), ("e_10410", "e_10410"), ("e_trap", "e_trap"), ("e_cusp", "e_cusp"), ("e_zac", "e_zac"),
+                  ("t50", "t50_pre"), ("tail_tau", "tail_τ"), ("e_313_inv", "e_313_inv")):
+        a, b = _np(res[rc]), ora[c]
+        tol = 2e-3 if c == "t50" else 4 * parity.ATOL[c] + 4 * parity.RTOL * np.abs(b)
+        assert (np.abs(a - b) > tol).sum() <= 1, (c, np.abs(a - b).max())
+    # against the full-rate chain: same physics, a different sampling of it
+    fused = ldsp.table_columns(ldsp.icpc_run(wf, ldsp.lower_icpc(cfg, tau, {}, L, 0.0, DT)))
+    np.testing.assert_allclose(_np(res.blmean) / rate, _np(fused["blmean"]), rtol=1e-5)
+    np.testing.assert_allclose(_np(res.e_10410) / rate, _np(fused["e_10410"]), rtol=2e-3)
+    np.testing.assert_allclose(_np(res.e_max), _np(fused["e_max"]), rtol=1e-4, atol=0.01)
+    for c in ("t10", "t50", "t90"):    # the windowed pole-zero sum starts at the window, not at the trace start
+        np.testing.assert_allclose(_np(res[c]), _np(fused[c]), atol=5e-3, err_msg=c)
+    np.testing.assert_allclose(_np(res.t50_pre), _np(fused["t50"]), atol=0.05)
+    assert bool((res.t0 < res.t50).all()) and bool((res.t50 < res.t90).all())
