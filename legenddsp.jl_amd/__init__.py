@@ -11,7 +11,7 @@ from ._lib import Context, LdspError, build, default_context
 from .config import (DSPConfig, PropDict, ClosedInterval, StepRange, get_fltpars, lower_icpc, lower_sipm,
                      reference_test_icpc_config, reference_test_sipm_config, plumbing_icpc_config_4096,
                      ns, us, ms, WindowError)
-from .routines import (ArrayOfRDWaveforms, Table, dsp_icpc, dsp_sipm, icpc_run, icpc_pz_trap_run, sipm_run, table_columns,
+from .routines import (ArrayOfRDWaveforms, Table, dsp_icpc, dsp_sipm, dsp_sipm_compressed, icpc_run, icpc_pz_trap_run, sipm_run, table_columns,
                        get_t0, get_threshold, get_qdrift, get_intracePileUp)
 from .filters import (SamplingInfo, smplinfo, fltinstance, rdfilt_, flt_output_length, flt_input_length,
                       flt_output_time_axis, InvCRFilter, IntegratorFilter, TrapezoidalChargeFilter, CUSPChargeFilter,
@@ -20,7 +20,7 @@ from .filters import (SamplingInfo, smplinfo, fltinstance, rdfilt_, flt_output_l
 from .optimization import (dsp_trap_rt_optimization, dsp_trap_ft_optimization, dsp_cusp_rt_optimization, dsp_zac_rt_optimization,
                            dsp_cusp_ft_optimization, dsp_zac_ft_optimization, dsp_sg_optimization, dsp_qc_flt_optimization, dsp_qdrift_flt_optimization, trap_grid_run, fir_grid_run, lower_trap_grid,
                            cuspzac_grid_taps)
-from .thin_routines import dsp_decay_times, dsp_puls
+from .thin_routines import dsp_decay_times, dsp_puls, dsp_pmts
 from .compressed import dsp_icpc_compressed, slope_residual_sigma
 from .ml_routines import get_qc_classifier, get_qc_classifier_compressed, qc_features, RbfSvmPredictor
 from .extractors import (VectorOfVectors, signalstats, tailstats, extremestats, thresholdstats, thresholdstats_mad,

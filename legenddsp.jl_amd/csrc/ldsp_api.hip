@@ -48,6 +48,9 @@ int ldsp_check_batch(ldsp_ctx* c, const void* x, int64_t n, int32_t L, const cha
   if (n > 0 && !x) return fail(LDSP_ERR_INVALID_ARG, "%s: waveform pointer is NULL", who);
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return fail(LDSP_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+  // an error another library left behind on this thread (e.g. a failed pointer-attribute probe of the host program) must
+  // not be reported as the failure of the launch below, which reads hipGetLastError() after it
+  (void)hipGetLastError();
   return LDSP_OK;
 }
 
@@ -465,7 +468,7 @@ int ldsp_fir_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgr
   const size_t ntap = (size_t)G * (size_t)Lf;
   if (ntap > c->fir_grid_cap) {   // grow-only tap buffer
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(c->d_fir_grid); (void)hipFree(c->d_sg_grid); c->d_fir_grid = nullptr; c->fir_grid_cap = 0;
+    (void)hipFree(c->d_fir_grid); c->d_fir_grid = nullptr; c->fir_grid_cap = 0;
     HIP_TRY(hipMalloc(&c->d_fir_grid, ntap * sizeof(float)));
     c->fir_grid_cap = ntap;
   }

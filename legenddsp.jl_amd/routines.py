@@ -182,12 +182,12 @@ def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None
     return sc, trig
 
 
-def dsp_sipm(data: Table, config: dict, pars_optimization: dict, ctx: _lib.Context = None) -> Table:
+def dsp_sipm(data: Table, config: dict, pars_optimization: dict, ctx: _lib.Context = None, _waveform_column="waveform") -> Table:
     """`dsp_sipm(data::Table, config::PropDict, pars_optimization::PropDict)` — reference
     src/dsp_sipm.jl:47-158: 24 scalar columns (4 passthrough) + 12 ragged VectorOfVectors columns,
     names as at dsp_sipm.jl:141-157.  Trigger times are in the time-axis unit (ns)."""
     from .extractors import _compact
-    wvfs: ArrayOfRDWaveforms = data["waveform"]
+    wvfs: ArrayOfRDWaveforms = data[_waveform_column]
     params = lower_sipm(config, pars_optimization, wvfs.nsamples, wvfs.t_first, wvfs.dt)
     sc, trig = sipm_run(wvfs.signal, params, ctx)
     s = {c: sc[i] for i, c in enumerate(_abi.SIPM_SCALAR_COLS)}
@@ -207,6 +207,13 @@ def dsp_sipm(data: Table, config: dict, pars_optimization: dict, ctx: _lib.Conte
     res["trig_pos_DC_trap"] = vv("trig_DC_trap", "x"); res["trig_pos_high_DC_trap"] = vv("trig_DC_trap", "x_high")
     res["trig_pos_tot_DC_trap"] = vv("trig_DC_trap", "x_tot"); res["trig_max_DC_trap"] = vv("trig_DC_trap", "max")
     return res
+
+
+def dsp_sipm_compressed(data: Table, config: dict, pars_optimization: dict, ctx: _lib.Context = None) -> Table:
+    """`dsp_sipm_compressed(data, config, pars_optimization)` — reference src/dsp_sipm.jl:207-318: the chain of `dsp_sipm`
+    on the `waveform_bit_drop` column.  `decode_data` (LegendDataTypes, :248) is the I/O side's codec: the column is taken
+    as a decoded ArrayOfRDWaveforms."""
+    return dsp_sipm(data, config, pars_optimization, ctx, _waveform_column="waveform_bit_drop")
 
 
 # ---------------------------------------------------------------------------

@@ -1,12 +1,13 @@
-"""Thin recombinations of the hot path's stages: `dsp_decay_times` (reference src/dsp_decaytime.jl:11-26)
-and `dsp_puls` (src/dsp_puls.jl:29-65), spelled with the filter-functor / extractor entry points."""
+"""Thin recombinations of the hot path's stages: `dsp_decay_times` (reference src/dsp_decaytime.jl:11-26),
+`dsp_puls` (src/dsp_puls.jl:29-65) and `dsp_pmts` (src/dsp_pmts.jl:3-65), spelled with the filter-functor / extractor
+entry points."""
 from __future__ import annotations
 
 import torch
 
 from .config import DSPConfig
-from .extractors import signalstats, tailstats
-from .filters import TrapezoidalChargeFilter, shift_waveform
+from .extractors import IntersectMaximum, extremestats, saturation, signalstats, tailstats
+from .filters import SavitzkyGolayFilter, TrapezoidalChargeFilter, shift_waveform
 from .routines import ArrayOfRDWaveforms, Table, get_threshold
 
 _US = 1000.0  # ns per us
@@ -38,4 +39,31 @@ def dsp_puls(data: Table, config: DSPConfig) -> Table:
     res["blmean"], res["blsigma"], res["blslope"], res["bloffset"] = st["mean"], st["sigma"], st["slope"], st["offset"]
     res["t50"], res["e_max"], res["e_10410"] = t50, wvf_max, e_10410
     res["blfc"], res["timestamp"], res["eventID_fadc"], res["e_fc"] = data["baseline"], data["timestamp"], data["eventnumber"], data["daqenergy"]
+    return res
+
+
+def dsp_pmts(data: Table, config: dict) -> Table:
+    """`dsp_pmts(data, config)` — reference src/dsp_pmts.jl:3-65.  `decode_data` (:20) is the I/O side's codec: the
+    `waveform` column is taken decoded.  `TimeAxisFilter(time_axis_step_length)` (src/timeaxis.jl:31-60) only replaces the
+    sampling step of the time axis.  `wsg_weight != 0` selects the WeightedSavitzkyGolayFilter of
+    src/alternative_filters.jl, which is outside the hot path: it raises."""
+    cfg = config
+    if int(cfg["wsg_weight"]) != 0:
+        raise NotImplementedError("WeightedSavitzkyGolayFilter (reference src/alternative_filters.jl) is out of scope; wsg_weight = 0 "
+                                  "selects the plain SavitzkyGolayFilter (src/dsp_pmts.jl:44-45)")
+    w0: ArrayOfRDWaveforms = data["waveform"]
+    wvfs = ArrayOfRDWaveforms(w0.signal, w0.t_first, float(cfg["time_axis_step_length"]))   # TimeAxisFilter: offset 0
+    bl = signalstats(wvfs, cfg["baseline_window_start"], cfg["baseline_window_end"])
+    wf_blsub = shift_waveform(wvfs, -bl["mean"])
+    raw = extremestats(wf_blsub)
+    trig = IntersectMaximum(cfg["min_tot_intersect"], cfg["max_tot_intersect"])(wf_blsub, float(cfg["intersect_threshold"]))
+    sat = saturation(wvfs, cfg["saturation_limit_low"], cfg["saturation_limit_high"])
+    pulse = extremestats(SavitzkyGolayFilter(cfg["wsg_window_length"], int(cfg["wsg_flt_degree"]), 0)(wf_blsub))
+    res = Table()
+    res["timestamp"], res["eventID_fadc"], res["e_fc"], res["channel"] = data["timestamp"], data["eventnumber"], data["daqenergy"], data["channel"]
+    res["raw_pulse_height"], res["raw_pulse_low"], res["raw_t0_hi"], res["raw_t0_low"] = raw["max"], raw["min"], raw["tmax"], raw["tmin"]
+    res["trig_max"], res["trig_t"], res["trig_mult"] = trig["max"], trig["x"], trig["multiplicity"]
+    res["sat_low"], res["sat_high"] = sat["low"], sat["high"]
+    res["pulse_height"], res["pulse_low"], res["t0_hi"], res["t0_low"] = pulse["max"], pulse["min"], pulse["tmax"], pulse["tmin"]
+    res["bl_mean"], res["bl_sigma"], res["bl_slope"] = bl["mean"], bl["sigma"], bl["slope"]
     return res

@@ -66,6 +66,11 @@ def test_sipm_reference_fixture_properties():
         v = res[c].cpu()
         assert bool(((v >= 0) & (v <= 100.0)).all())
     assert len(res.trig_pos) == 10
+    # dsp_sipm_compressed (src/dsp_sipm.jl:207-318): the same chain on the decoded `waveform_bit_drop` column
+    data2 = ldsp.Table({("waveform_bit_drop" if k == "waveform" else k): v for k, v in data.items()})
+    res2 = ldsp.dsp_sipm_compressed(data2, cfg, {"sg": {"wl": 200 * ldsp.ns}})
+    assert res2.columnnames == res.columnnames
+    assert torch.equal(res2.threshold, res.threshold) and torch.equal(res2.trig_pos.values, res.trig_pos.values)
 
 
 @pytest.mark.parametrize("L", [6250, 5000, 3500, 12001])

@@ -145,3 +145,41 @@ def test_thin_routines_dsp_decay_times_and_dsp_puls(orc):
     t_ref = np.array([orc.intersect(xs[i], 0.5 * xs[i].max(), ldsp.config.nsamples(1000.0, 16.0), 0.0, 16.0)["x"] for i in range(n)]) / 1000.0
     np.testing.assert_allclose(r["t50"].cpu().numpy(), np.nan_to_num(t_ref), atol=5e-4)
     assert torch.equal(r["eventID_fadc"], torch.arange(1, n + 1))
+
+
+def test_thin_routine_dsp_pmts(orc):
+    """dsp_pmts (reference src/dsp_pmts.jl:3-65) through the functor entry points, against the oracle's functors."""
+    n, Lp, dt = 24, 1024, 4.0
+    g = torch.Generator().manual_seed(3)
+    sig = 100.0 + torch.randn(n, Lp, generator=g) * 0.8
+    for i in range(n):                                   # a few negative-going-then-positive pulses of 12..40 samples
+        for k in range(1 + i % 3):
+            s = 200 + 250 * k + 7 * i
+            sig[i, s:s + 12 + 4 * k] += 30.0 + 5.0 * k
+    sig[0, 900:905] = 4095.0                             # saturated samples
+    wv = ldsp.ArrayOfRDWaveforms(sig.cuda(), 0.0, 16.0)   # the stored step is replaced by time_axis_step_length
+    cfg = dict(time_axis_step_length=dt, baseline_window_start=0.0, baseline_window_end=600.0, min_tot_intersect=8.0,
+               max_tot_intersect=400.0, intersect_threshold=10.0, wsg_window_length=28.0, wsg_flt_degree=2, wsg_weight=0,
+               saturation_limit_high=4095.0, saturation_limit_low=0.0)
+    data = ldsp.Table(waveform=wv, timestamp=torch.arange(n), channel=torch.full((n,), 7), eventnumber=torch.arange(1, n + 1), daqenergy=torch.zeros(n))
+    r = ldsp.dsp_pmts(data, cfg)
+    assert r.columnnames == ["timestamp", "eventID_fadc", "e_fc", "channel", "raw_pulse_height", "raw_pulse_low", "raw_t0_hi", "raw_t0_low",
+                             "trig_max", "trig_t", "trig_mult", "sat_low", "sat_high", "pulse_height", "pulse_low", "t0_hi", "t0_low",
+                             "bl_mean", "bl_sigma", "bl_slope"]
+    x = sig.numpy().astype(np.float64)
+    h = orc.sg_coeffs(7, 2, 0)
+    for i in range(n):
+        st = orc.signalstats(x[i], 0, 150, 0.0, dt)
+        assert float(r["bl_mean"][i]) == pytest.approx(st["mean"], abs=2e-4) and float(r["bl_sigma"][i]) == pytest.approx(st["sigma"], rel=1e-4)
+        xs = x[i] - st["mean"]
+        assert float(r["raw_pulse_height"][i]) == pytest.approx(xs.max(), abs=2e-3)
+        assert float(r["raw_t0_hi"][i]) == pytest.approx(dt * int(np.argmax(xs)), abs=1e-3)
+        o = orc.intersect_maximum(xs, 10.0, 2, 100, 0.0, dt)
+        assert int(r["trig_mult"][i]) == o["multiplicity"] == 1 + i % 3 + (i == 0)   # trace 0: + the saturated burst
+        np.testing.assert_allclose(r["trig_t"][i].cpu().numpy(), o["x"], atol=0.02)
+        np.testing.assert_allclose(r["trig_max"][i].cpu().numpy(), o["max"], atol=2e-3)
+        sm = orc.fir(xs, h)
+        assert float(r["pulse_height"][i]) == pytest.approx(sm.max(), abs=2e-3)
+    assert int(r["sat_high"][0]) == 5 and int(r["sat_high"][1:].sum()) == 0
+    with pytest.raises(NotImplementedError):
+        ldsp.dsp_pmts(data, dict(cfg, wsg_weight=2))
