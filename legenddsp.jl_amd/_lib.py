@@ -14,7 +14,7 @@ from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SO = os.path.join(_CSRC, "libldsp_hip.so")
+_SO = os.environ.get("LDSP_HIP_LIB") or os.path.join(_CSRC, "libldsp_hip.so")   # LDSP_HIP_LIB: another build of the same ABI (tuning experiments)
 
 
 class LdspError(RuntimeError):

@@ -93,3 +93,11 @@ def test_intersect_interpolates_linearly(orc):
     r = orc.intersect(y, 2.0, 2, 10.0, 2.0)
     assert r["x"] == pytest.approx(10.0 + 2.0 * 2.5) and r["multiplicity"] == 2
     assert math.isnan(orc.intersect(y, 5.0, 2, 10.0, 2.0)["x"])
+
+
+def test_sg_coefficients_equal_scipy(orc):
+    """Independent implementation of assumption A2's coefficients: scipy.signal.savgol_coeffs in its convolution
+    orientation (the orientation the oracle's `fir` and the HIP `ldsp_rdfilt_fir` take)."""
+    from scipy.signal import savgol_coeffs
+    for n, d, der in ((5, 2, 1), (7, 3, 1), (13, 3, 1), (7, 2, 0), (9, 4, 2), (3, 2, 1)):
+        np.testing.assert_allclose(orc.sg_coeffs(n, d, der), savgol_coeffs(n, d, deriv=der, use="conv"), atol=1e-13)
