@@ -71,6 +71,12 @@ int ldsp_ctx_set_option(ldsp_ctx* ctx, const char* key, int64_t value);
 /* sizeof() of the ABI structs as compiled: 0 icpc_params, 1 icpc_out,
  * 2 sipm_params, 3 sipm_out, 4 trig_out (binding self-check). */
 int64_t ldsp_abi_sizeof(int which);
+/* dsp_icpc_compressed, windowed traces (src/dsp_icpc.jl:352-353: shift_waveform.(wvfs_wdw, -bl_stats.mean ./ presum_rate)):
+ * the following ldsp_icpc_run calls on this context subtract scale * per_trace[i] (device pointer, [n]) instead of the
+ * trace's own signalstats(bl_window).mean; blmean then reports that value.  NULL restores the default.
+ * Option "icpc_main_only" (ldsp_ctx_set_option) runs dsp_icpc without the CUSP/ZAC stage: e_cusp, e_zac, e_cusp_max,
+ * e_zac_max, t_cusp_max, t_zac_max are not written (the windowed traces are shorter than those filters). */
+int ldsp_ctx_set_baseline(ldsp_ctx*, const float* per_trace, double scale);
 /* Average duration in ms of the launches issued by the last ldsp_*_run call,
  * measured with hipEvents recorded on the context stream (timing must have
  * been enabled; synchronises on the closing event). */

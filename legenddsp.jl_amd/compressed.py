@@ -3,9 +3,10 @@ LEGEND data stores per event — `waveform_presummed` (the whole trace summed in
 baseline, tail) and `waveform_windowed` (full sampling rate around the rise: timing, current).
 
 `decode_data` (LegendDataTypes, :319-320) is the I/O side's codec and stays there: both columns are taken as decoded
-ArrayOfRDWaveforms.  The presummed traces run through the fused kernel (`ldsp_icpc_run`, parameters lowered for their
-sampling step, rail and SG window scaled by the rate); the windowed traces — short, with the baseline handed over from the
-presummed ones — through the filter-functor / extractor entry points, statement by statement as the reference spells them.
+ArrayOfRDWaveforms.  Two launches of the fused kernel (`ldsp_icpc_run`): the presummed traces with parameters lowered for
+their sampling step (rail and SG window scaled by the rate), then the windowed traces — short, with the baseline handed over
+from the presummed ones (`ldsp_ctx_set_baseline`) and without the CUSP/ZAC stage.  `fused_windowed=False` spells the
+windowed half statement by statement through the filter-functor / extractor entry points instead (the comparator).
 """
 from __future__ import annotations
 
@@ -27,8 +28,55 @@ def slope_residual_sigma(st: dict, n: int, dt: float) -> torch.Tensor:
     return v.clamp_min(0.0).sqrt().float()
 
 
+WINDOWED_COLS = ("e_max", "e_min", "t0", "t10", "t50", "t80", "t90", "t99", "drift_time", "qdrift", "lq", "a_raw", "a_sg", "a_60", "a_100", "t0_inv")
+
+
+def windowed_columns(wdw: ArrayOfRDWaveforms, blmean_pre: torch.Tensor, rate: int, config: DSPConfig, tau: float, pars_filter: dict,
+                     ctx: _lib.Context = None) -> dict:
+    """The columns `dsp_icpc_compressed` takes from the windowed traces (:352-353, :362-393, :431-435, :452-459), by ONE launch
+    of the fused kernel: baseline = blmean of the presummed trace / rate (`ldsp_ctx_set_baseline`), no CUSP/ZAC stage
+    (option `icpc_main_only`), parameters lowered for the window's own time axis."""
+    x = wdw.signal
+    ctx = ctx or _lib.default_context(x.device.index)
+    pw = lower_icpc(config, tau, pars_filter, wdw.nsamples, wdw.t_first, wdw.dt, windowed=True)
+    bl = blmean_pre.to(device=x.device, dtype=torch.float32).contiguous()
+    ctx.set_baseline(bl, 1.0 / float(rate))
+    ctx.set_option("icpc_main_only", 1)
+    try:
+        B = table_columns(icpc_run(x, pw, ctx))
+    finally:
+        ctx.set_baseline(None)
+        ctx.set_option("icpc_main_only", 0)
+    return {k: B[k] for k in WINDOWED_COLS}
+
+
+def windowed_columns_unfused(wdw: ArrayOfRDWaveforms, blmean_pre: torch.Tensor, rate: int, config: DSPConfig, tau: float,
+                             pars_filter: dict) -> dict:
+    """The same columns statement by statement through the filter-functor / extractor entry points, as the reference spells
+    them (the comparator of `windowed_columns` in tests/test_compressed_gpu.py)."""
+    kw = config.kwargs_pars
+    w = shift_waveform(wdw, -blmean_pre / float(rate))
+    wmax, wmin = w.signal.amax(dim=1), w.signal.amin(dim=1)
+    w = InvCRFilter(float(tau))(w)
+    t0 = get_t0(w, config.t0_threshold, flt_pars=tuple(kw.t0_flt_pars), mintot=kw.t0_mintot)
+    tx = {f: get_threshold(w, wmax * f, mintot=kw.tx_mintot) for f in (0.1, 0.5, 0.8, 0.9, 0.99)}
+    qd = (config.qdrift_int_length.first, config.qdrift_int_length.last)
+    lqr = (config.lq_int_length.first, config.lq_int_length.last)
+    cw = config.current_window
+    sg_wl = get_fltpars(pars_filter, "sg", config)
+    res = dict(e_max=wmax, e_min=wmin, t0=t0, t10=tx[0.1], t50=tx[0.5], t80=tx[0.8], t90=tx[0.9], t99=tx[0.99],
+               drift_time=(tx[0.9] - t0) * 1000.0)        # uconvert(ns, t90 - t0)
+    res["qdrift"] = get_qdrift(w, t0, qd, pol_power=kw.int_interpolation_order, sign_est_length=kw.int_interpolation_length)
+    res["lq"] = get_qdrift(w, tx[0.8], lqr, pol_power=kw.int_interpolation_order, sign_est_length=kw.int_interpolation_length)
+    res["a_raw"] = get_wvf_maximum(DerivativeFilter(1.0)(w), cw.left, cw.right)
+    for k, wl in (("a_sg", sg_wl), ("a_60", 60.0), ("a_100", 100.0)):
+        res[k] = get_wvf_maximum(SavitzkyGolayFilter(wl, config.sg_flt_degree, 1)(w), cw.left, cw.right)
+    res["t0_inv"] = get_t0(multiply_waveform(w, -1.0), config.t0_threshold, flt_pars=DEFAULT_T0_FLT_PARS, mintot=kw.t0_mintot)
+    return res
+
+
 def dsp_icpc_compressed(data: Table, config: DSPConfig, tau: float, pars_filter: dict, f_evaluate_qc=None,
-                        ctx: _lib.Context = None) -> Table:
+                        ctx: _lib.Context = None, fused_windowed: bool = True) -> Table:
     """`dsp_icpc_compressed(data, config, τ, pars_filter; f_evaluate_qc)` — reference src/dsp_icpc.jl:293-499, same column
     names.  Required columns: waveform_presummed, waveform_windowed, presum_rate, baseline, timestamp, eventnumber,
     daqenergy, t_sat_lo, t_sat_hi, deadtime."""
@@ -55,23 +103,12 @@ def dsp_icpc_compressed(data: Table, config: DSPConfig, tau: float, pars_filter:
             st["mean"] = st["mean"] - A["blmean"]
         aux[name] = (st, slope_residual_sigma(st, npts(win), pre.dt))
 
-    # ---- windowed traces, statement by statement  (:352-353, :362-363, :371-393, :431-435, :452-459)
-    w = shift_waveform(wdw, -A["blmean"] / float(rate))
-    wmax, wmin = w.signal.amax(dim=1), w.signal.amin(dim=1)
-    w = InvCRFilter(float(tau))(w)
-    t0 = get_t0(w, config.t0_threshold, flt_pars=tuple(kw.t0_flt_pars), mintot=kw.t0_mintot)
-    tx = {f: get_threshold(w, wmax * f, mintot=kw.tx_mintot) for f in (0.1, 0.5, 0.8, 0.9, 0.99)}
-    drift_time = (tx[0.9] - t0) * 1000.0        # uconvert(ns, t90 - t0)
-    qd = (config.qdrift_int_length.first, config.qdrift_int_length.last)
-    lqr = (config.lq_int_length.first, config.lq_int_length.last)
-    qdrift = get_qdrift(w, t0, qd, pol_power=kw.int_interpolation_order, sign_est_length=kw.int_interpolation_length)
-    lq = get_qdrift(w, tx[0.8], lqr, pol_power=kw.int_interpolation_order, sign_est_length=kw.int_interpolation_length)
-    cw = config.current_window
-    sg_wl = get_fltpars(pars_filter, "sg", config)
-    a_raw = get_wvf_maximum(DerivativeFilter(1.0)(w), cw.left, cw.right)
-    a = {k: get_wvf_maximum(SavitzkyGolayFilter(wl, config.sg_flt_degree, 1)(w), cw.left, cw.right)
-         for k, wl in (("a_sg", sg_wl), ("a_60", 60.0), ("a_100", 100.0))}
-    t0_inv = get_t0(multiply_waveform(w, -1.0), config.t0_threshold, flt_pars=DEFAULT_T0_FLT_PARS, mintot=kw.t0_mintot)
+    # ---- windowed traces: the fused chain again, without its CUSP/ZAC stage, the baseline handed over  (:352-353)
+    W = windowed_columns(wdw, A["blmean"], rate, config, tau, pars_filter, ctx) if fused_windowed else \
+        windowed_columns_unfused(wdw, A["blmean"], rate, config, tau, pars_filter)
+    wmax, wmin, t0, t0_inv, drift_time, qdrift, lq, a_raw = (W[k] for k in ("e_max", "e_min", "t0", "t0_inv", "drift_time", "qdrift", "lq", "a_raw"))
+    tx = {0.1: W["t10"], 0.5: W["t50"], 0.8: W["t80"], 0.9: W["t90"], 0.99: W["t99"]}
+    a = {k: W[k] for k in ("a_sg", "a_60", "a_100")}
 
     if f_evaluate_qc is None:
         qc = torch.full((n,), -1, dtype=torch.int64, device=dev)

@@ -216,7 +216,7 @@ DEFAULT_T0_FLT_PARS = (40.0 * ns, 100.0 * ns, 2000.0 * ns)  # src/dsp_routines.j
 
 
 def lower_icpc(config: DSPConfig, tau: float, pars_filter: dict, L: int, t_first: float, dt: float,
-               presum_rate: int = None) -> _abi.IcpcParams:
+               presum_rate: int = None, windowed: bool = False) -> _abi.IcpcParams:
     """Lower (DSPConfig, tau, pars_filter) + sampling info of the traces to ldsp_icpc_params.
 
     Follows the parameter unpacking of reference src/dsp_icpc.jl:64-99.  `presum_rate` (dsp_icpc_compressed, :293-350,
@@ -233,6 +233,8 @@ def lower_icpc(config: DSPConfig, tau: float, pars_filter: dict, L: int, t_first
     p.bl_until = window_index(config.bl_window.right, t_first, dt)
     p.tail_from = window_index(config.tail_window.left, t_first, dt)
     p.tail_until = window_index(config.tail_window.right, t_first, dt)
+    if windowed:
+        p.bl_from, p.bl_until, p.tail_from, p.tail_until = 0, min(7, L - 1), 0, min(7, L - 1)
     _check_window("bl_window", p.bl_from, p.bl_until, L)
     _check_window("tail_window", p.tail_from, p.tail_until, L)
     p.pz_c = float(dt) / float(tau)
@@ -274,6 +276,15 @@ def lower_icpc(config: DSPConfig, tau: float, pars_filter: dict, L: int, t_first
     p.intrace_nsigma = float(config.inTraceCut_std_threshold)
     p.intrace_mintot = max(1, nsamples(kw.intrace_mintot, dt))
     p.bl_left, p.bl_right = config.bl_window.left, config.bl_window.right
+    if windowed:
+        tiny = trap_samples(dt, 0.0, dt)
+        for i in range(3):
+            if p.trap_fixed[i].flen > L:
+                p.trap_fixed[i] = tiny
+        if p.trap_opt.flen + p.sig_est.npts > L:
+            p.trap_opt = tiny
+        p.cusp = p.zac = _abi.CuspZac(1.0, 0, 5, 1.0e9, 5.0)
+        p.bl_left, p.bl_right = 0.0, float(t_first) + (p.sg_npts[0] - 1 + 8) * float(dt)   # 9 samples of the SG axis
     validate_icpc(p)
     return p
 

@@ -714,7 +714,9 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   }
   __syncthreads();
   // every thread needs the mean; sigma / slope / offset (double divisions, sqrt) only thread 0
-  const float blmean = (float)((double)pv_bl + win_collect1<NW>(S.wsum, 0) * P.bl.inv_n);
+  float blmean_ = (float)((double)pv_bl + win_collect1<NW>(S.wsum, 0) * P.bl.inv_n);
+  if (P.ext_bl) blmean_ = P.ext_bl[blockIdx.x] * P.ext_bl_scale;   // windowed traces of dsp_icpc_compressed (dsp_icpc.jl:353)
+  const float blmean = blmean_;
   if (tid == 0) {
     float m_, blsigma, blslope, bloffset;
     win_finish(win_collect<NW>(S.wsum, 0), P.bl, pv_bl, P.t_first, P.dt, &m_, &blsigma, &blslope, &bloffset);

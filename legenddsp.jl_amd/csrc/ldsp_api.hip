@@ -128,7 +128,15 @@ int ldsp_ctx_set_option(ldsp_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "two_kernel")) { c->two_kernel = value != 0; return LDSP_OK; }
   if (!strcmp(key, "sipm_generic")) { c->sipm_generic = value != 0; return LDSP_OK; }
   if (!strcmp(key, "dbg_stop")) { c->dbg_stop = (int)value; c->icpc_valid = false; return LDSP_OK; }
+  if (!strcmp(key, "icpc_main_only")) { c->icpc_main_only = value != 0; return LDSP_OK; }
   return fail(LDSP_ERR_INVALID_ARG, "unknown option '%s'", key);
+}
+
+int ldsp_ctx_set_baseline(ldsp_ctx* c, const float* per_trace, double scale) {
+  if (!c) return fail(LDSP_ERR_INVALID_ARG, "ctx is NULL");
+  c->ext_bl = per_trace; c->ext_bl_scale = (float)scale;
+  c->icpc_valid = false;   // the device parameter block carries the pointer
+  return LDSP_OK;
 }
 
 int ldsp_ctx_enable_timing(ldsp_ctx* c, int on) {
@@ -346,6 +354,7 @@ static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p) {
   if (rc) return rc;
   d.h_cusp = c->d_hc; d.h_zac = c->d_hz;
   d.dbg_stop = c->dbg_stop;
+  d.ext_bl = c->ext_bl; d.ext_bl_scale = c->ext_bl_scale;
   c->icpc_host = d;
   HIP_TRY(hipMemcpyAsync(c->d_icpc, &c->icpc_host, sizeof(IcpcDev), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_hc, hc.data(), sizeof(float) * hc.size(), hipMemcpyHostToDevice, c->stream));
@@ -379,7 +388,8 @@ int ldsp_icpc_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_param
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   int stages = 1;
   HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->icpc_host.L == 16 * c->icpc_host.NT, c->d_icpc, c->d_aux, od, c->icpc_host.cusp_mode == 0,
-                      c->icpc_host.cz_shared != 0, !c->two_kernel, c->dbg_stop > 0 && c->dbg_stop < 10,
+                      c->icpc_host.cz_shared != 0, !c->two_kernel && !c->icpc_main_only,
+                      c->icpc_main_only || (c->dbg_stop > 0 && c->dbg_stop < 10),
                       ((std::max(c->icpc_host.cusp.Lf, c->icpc_host.zac.Lf) + 2 + 7) & ~3), c->stream,
                       c->timing ? c->evm : nullptr, &stages));
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = stages; }

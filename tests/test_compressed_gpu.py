@@ -124,3 +124,34 @@ def test_presummed_and_windowed_pair_rate4(orc):
         np.testing.assert_allclose(_np(res[c]), _np(fused[c]), atol=5e-3, err_msg=c)
     np.testing.assert_allclose(_np(res.t50_pre), _np(fused["t50"]), atol=0.05)
     assert bool((res.t0 < res.t50).all()) and bool((res.t50 < res.t90).all())
+
+
+@pytest.mark.parametrize("L_w,w0", [(3000, 2000), (2048, 2400), (4096, 1500)])
+def test_fused_windowed_half_equals_functor_spelling(L_w, w0):
+    """`windowed_columns` (one launch of the fused kernel with the baseline handed over, no CUSP/ZAC stage) against the
+    reference's statement-by-statement spelling through the functor entry points."""
+    from legenddsp_jl_amd.compressed import windowed_columns, windowed_columns_unfused, WINDOWED_COLS
+    n, L, rate = 256, 8192, 4
+    cfg = ldsp.reference_test_icpc_config()
+    tau = 500 * ldsp.us
+    wf = ldsp.synth.hpge_batch(n, L, device="cuda", seed=23 + L_w)
+    wdw = ldsp.ArrayOfRDWaveforms(wf[:, w0:w0 + L_w].contiguous(), w0 * DT, DT)
+    bl_pre = wf[:, :2400].mean(dim=1) * rate + torch.linspace(-2.0, 2.0, n, device="cuda")     # any per-trace value
+    f = windowed_columns(wdw, bl_pre, rate, cfg, tau, {})
+    u = windowed_columns_unfused(wdw, bl_pre, rate, cfg, tau, {})
+    assert set(f) == set(u) == set(WINDOWED_COLS)
+    for c in ("e_max", "e_min"):
+        np.testing.assert_allclose(_np(f[c]), _np(u[c]), rtol=1e-6, atol=2e-3, err_msg=c)
+    for c in ("t0", "t10", "t50", "t80", "t90", "t99", "t0_inv"):
+        bad = np.abs(_np(f[c]) - _np(u[c])) > 1e-3
+        assert bad.sum() <= 1, (c, _np(f[c])[bad], _np(u[c])[bad])
+    assert (np.abs(_np(f["drift_time"]) - _np(u["drift_time"])) > 1.5).sum() <= 1
+    for c in ("qdrift", "lq"):
+        np.testing.assert_allclose(_np(f[c]), _np(u[c]), rtol=3e-4, atol=60, err_msg=c)
+    for c in ("a_sg", "a_60", "a_100", "a_raw"):
+        a, b = _np(f[c]), _np(u[c])
+        assert (np.abs(a - b) > 1e-2 + 1e-4 * np.abs(b)).sum() <= 3, c
+    # the context is back in its default state: a plain run afterwards is the plain chain
+    p = ldsp.lower_icpc(cfg, tau, {}, L, 0.0, DT)
+    t1 = ldsp.icpc_run(wf[:8].contiguous(), p)
+    assert bool(torch.isfinite(ldsp.table_columns(t1)["e_cusp"]).all())
