@@ -18,9 +18,10 @@ from .filters import (SamplingInfo, smplinfo, fltinstance, rdfilt_, flt_output_l
                       ZACChargeFilter, SavitzkyGolayFilter, DerivativeFilter, HaarAveragingFilter, MovingWindowFilter,
                       MovingWindowMultiFilter, TruncateFilter, shift_waveform, multiply_waveform, reverse_waveform)
 from .optimization import (dsp_trap_rt_optimization, dsp_trap_ft_optimization, dsp_cusp_rt_optimization, dsp_zac_rt_optimization,
-                           dsp_cusp_ft_optimization, dsp_zac_ft_optimization, dsp_sg_optimization, dsp_qc_flt_optimization, dsp_qdrift_flt_optimization, trap_grid_run, fir_grid_run, lower_trap_grid,
+                           dsp_cusp_ft_optimization, dsp_zac_ft_optimization, dsp_sg_optimization, dsp_sg_optimization_compressed, dsp_qc_flt_optimization, dsp_qc_flt_optimization_compressed, dsp_qdrift_flt_optimization, trap_grid_run, fir_grid_run, lower_trap_grid,
                            cuspzac_grid_taps)
-from .thin_routines import dsp_decay_times, dsp_puls, dsp_pmts
+from .thin_routines import (dsp_decay_times, dsp_puls, dsp_puls_compressed, dsp_pmts, dsp_sg_sipm_thresholds_compressed,
+                            dsp_sg_sipm_optimization_compressed)
 from .compressed import dsp_icpc_compressed, slope_residual_sigma
 from .ml_routines import get_qc_classifier, get_qc_classifier_compressed, qc_features, RbfSvmPredictor
 from .extractors import (VectorOfVectors, signalstats, tailstats, extremestats, thresholdstats, thresholdstats_mad,

