@@ -79,6 +79,7 @@ struct FirGridDev {
   float pick_fp;
   float offs[64];
   const float* taps;   // device, [G][Lf], taps REVERSED (correlation form: out[k] = sum_j c[j] y[k+j])
+  int32_t same_offs;   // every grid point picks off at the same position (always so for the CUSP / ZAC scans)
 };
 
 // SG window-length grid scan (ldsp_sg_grid_run)

@@ -1647,6 +1647,62 @@ fir_grid_kernel(const float* __restrict__ wf, const FirGridDev* __restrict__ Pp,
     }
   }
   const int Lf = P.Lf, nout = L - Lf + 1;
+  if (P.same_offs) {
+    // Every grid point picks off at the same position, and the estimator is linear in its window:
+    //   E[g] = sum_l w[l] * (sum_j c_g[j] y[i0+l+j]) = sum_j c_g[j] * z[j],   z[j] = sum_l w[l] y[i0+l+j].
+    // z is ONE npts-tap pass over the trace (thread <-> j, consecutive lanes on consecutive LDS words); each grid point
+    // then costs one dot product with z (taps read coalesced from L2): (npts + G) * Lf multiply-adds per trace instead of
+    // npts * G * Lf.  Partial sums: per thread over its j, DPP inside the wave, wave partials combined in fixed order.
+    float* wpart = reinterpret_cast<float*>(slot + 8);                                // [NW][LDSP_MAX_GRID]
+    Pos p = (P.pick_mode == 1) ? pos_add(base, P.offs[0]) : base;
+    p.ip -= (Lf - 1);   // trailing alignment of the filter output (A1)
+    const int npts = P.est.npts;
+    if (nout < npts) {                                   // estimate(): window longer than the filter output
+      if (tid < P.G) out[(size_t)tid * (size_t)n + blockIdx.x] = NAN;
+      return;
+    }
+    if (p.ip < 0) { p.ip = 0; p.fp = 0.f; }              // the clamps of estimate()
+    if (p.ip >= nout - 1) { p.ip = nout - 1; p.fp = 0.f; }
+    int i0 = p.ip + (int)ceilf(p.fp - 0.5f * (float)npts);
+    i0 = max(0, min(i0, nout - npts));
+    const float u = ((float)(p.ip - i0) + p.fp - P.est.c) * P.est.s_inv;
+    const float wv = (lane < npts) ? est_weight(P.est, estB, lane, u) : 0.f;   // every wave holds the weights, lane l <-> point l
+    float acc[LDSP_MAX_GRID];
+#pragma unroll
+    for (int g = 0; g < LDSP_MAX_GRID; ++g) acc[g] = 0.f;
+    const int G = P.G;
+    for (int j0 = 0; j0 < Lf; j0 += NT) {
+      const int j = j0 + tid;
+      const bool in = j < Lf;
+      const float* yp = &Y[i0 + (in ? j : 0)];
+      float z0 = 0.f, z1 = 0.f;
+      int l = 0;
+      for (; l + 4 <= npts; l += 4) {
+        z0 = fmaf(readlane_f(wv, l), yp[l], z0); z1 = fmaf(readlane_f(wv, l + 1), yp[l + 1], z1);
+        z0 = fmaf(readlane_f(wv, l + 2), yp[l + 2], z0); z1 = fmaf(readlane_f(wv, l + 3), yp[l + 3], z1);
+      }
+      for (; l < npts; ++l) z0 = fmaf(readlane_f(wv, l), yp[l], z0);
+      const float z = in ? z0 + z1 : 0.f;
+      const float* taps = P.taps;
+      uint32_t idx = in ? (uint32_t)j : 0u;   // one 32-bit running index (G * Lf <= 2^19) on ONE scalar base: no per-point base pointers
+#pragma unroll
+      for (int g = 0; g < LDSP_MAX_GRID; ++g)
+        if (g < G) { acc[g] = fmaf(taps[idx], z, acc[g]); idx += (uint32_t)Lf; }   // (g < G: scalar test, the tail of the unrolled body is skipped)
+    }
+#pragma unroll
+    for (int g = 0; g < LDSP_MAX_GRID; ++g)
+      if (g < G) {
+        const float s = wave_sum_all(acc[g]);
+        if (lane == 0) wpart[wave * LDSP_MAX_GRID + g] = s;
+      }
+    __syncthreads();
+    if (tid < G) {
+      float e = 0.f;
+      for (int ww = 0; ww < NW; ++ww) e += wpart[ww * LDSP_MAX_GRID + tid];
+      out[(size_t)tid * (size_t)n + blockIdx.x] = e;
+    }
+    return;
+  }
   for (int g = wave; g < P.G; g += NW) {
     const float* c = P.taps + (size_t)g * (size_t)Lf;   // wave-uniform pointer: the tap reads are scalar loads
     Pos p = (P.pick_mode == 1) ? pos_add(base, P.offs[g]) : base;
@@ -1669,7 +1725,7 @@ fir_grid_kernel(const float* __restrict__ wf, const FirGridDev* __restrict__ Pp,
 template <int NT, int R, bool FULL>
 static hipError_t launch_fir_grid_t(const float* wf, int64_t n, const FirGridDev* dP, float* out, hipStream_t st) {
   constexpr int NW = NT / 64, Lp = 16 * NT;
-  const size_t smem = (size_t)(Lp + 64 + Lp / 32) * 4 + (R * NW + NW) * 8 + EST_TBL * 4 + 32;
+  const size_t smem = (size_t)(Lp + 64 + Lp / 32) * 4 + (R * NW + NW) * 8 + EST_TBL * 4 + 32 + (size_t)NW * LDSP_MAX_GRID * 4;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fir_grid_kernel<NT, R, FULL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;

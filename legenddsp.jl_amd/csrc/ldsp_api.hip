@@ -129,6 +129,7 @@ int ldsp_ctx_set_option(ldsp_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "sipm_generic")) { c->sipm_generic = value != 0; return LDSP_OK; }
   if (!strcmp(key, "dbg_stop")) { c->dbg_stop = (int)value; c->icpc_valid = false; return LDSP_OK; }
   if (!strcmp(key, "icpc_main_only")) { c->icpc_main_only = value != 0; return LDSP_OK; }
+  if (!strcmp(key, "fir_grid_per_point")) { c->fir_grid_per_point = value != 0; return LDSP_OK; }
   return fail(LDSP_ERR_INVALID_ARG, "unknown option '%s'", key);
 }
 
@@ -474,6 +475,9 @@ int ldsp_fir_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgr
   const double pos = (p->pick_time - p->t_first) / p->dt, fl = std::floor(pos);
   d.pick_ip = (int)fl; d.pick_fp = (float)(pos - fl);
   for (int g = 0; g < G; ++g) d.offs[g] = offsets ? (float)(offsets[g] / p->dt) : 0.f;
+  d.same_offs = 1;
+  for (int g = 1; g < G; ++g) d.same_offs &= (d.offs[g] == d.offs[0]);
+  if (c->fir_grid_per_point) d.same_offs = 0;
   HIP_TRY(hipSetDevice(c->device));
   const size_t ntap = (size_t)G * (size_t)Lf;
   if (ntap > c->fir_grid_cap) {   // grow-only tap buffer

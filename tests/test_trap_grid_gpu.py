@@ -183,3 +183,20 @@ def test_thin_routine_dsp_pmts(orc):
     assert int(r["sat_high"][0]) == 5 and int(r["sat_high"][1:].sum()) == 0
     with pytest.raises(NotImplementedError):
         ldsp.dsp_pmts(data, dict(cfg, wsg_weight=2))
+
+
+def test_fir_grid_linearity_form_equals_per_point_form():
+    """ldsp_fir_grid_run: the shared-pick-off form (one estimator-weighted pass z over the trace, then one dot product per grid
+    point) against the per-point evaluation of every filter output (option fir_grid_per_point), on rt and ft scans."""
+    cfg = ldsp.reference_test_icpc_config()
+    wvfs = ldsp.ArrayOfRDWaveforms(ldsp.synth.hpge_batch(48, L, device="cuda", seed=88), 0.0, 16.0)
+    ctx = ldsp.default_context()
+    for fn in (lambda: ldsp.dsp_cusp_rt_optimization(wvfs, cfg, 500 * ldsp.us, ctx=ctx),
+               lambda: ldsp.dsp_zac_ft_optimization(wvfs, cfg, 500 * ldsp.us, 8 * ldsp.us, ctx=ctx)):
+        fast = fn().clone()
+        ctx.set_option("fir_grid_per_point", 1)
+        try:
+            ref = fn().clone()
+        finally:
+            ctx.set_option("fir_grid_per_point", 0)
+        torch.testing.assert_close(fast, ref, rtol=2e-5, atol=0.05)
