@@ -7,7 +7,9 @@ over one batch of synthetic HPGe traces that is already resident in HBM.
   N = 1 : 1 M x 8192-sample float32 traces on one GPU (config 3).
   N > 1 : each rank owns its own 1 M-trace shard (weak scaling), runs the same
           kernel and the [n,48] output shards are gathered to rank 0 with one
-          RCCL gather inside the timed region (config 4 shape).
+          RCCL gather per batch inside the timed region (config 4 shape); the
+          gather of batch k overlaps the kernel of batch k+1 (double-buffered
+          tables, all gathers complete before the closing barrier).
 Prints ONE JSON line (rank 0).  `--workload pz_trap` times BASELINE config 2
 (blmean -> shift -> InvCR -> Trap(10us,4us) -> max) instead; `--workload sipm` times BASELINE
 config 5's shape (fused dsp_sipm, 16384-sample traces, 625 k per GPU by default).
@@ -148,17 +150,32 @@ def main():
     out = torch.empty((n, ncol), dtype=torch.float32, device=dev) if args.workload == "icpc" else \
         torch.empty((2, n), dtype=torch.float32, device=dev)
 
-    gathered = torch.empty((n * world, ncol), dtype=torch.float32, device=dev) if (world > 1 and rank == 0 and args.workload == "icpc") else None
+    # N > 1: the table of batch k travels to rank 0 (RCCL, its own stream) while the kernel of batch k+1 runs: two output
+    # tables per rank, two gathered tables on rank 0, and a table is overwritten only after its gather has completed
+    pipe = world > 1 and args.workload == "icpc"
+    outs = [out, torch.empty_like(out)] if pipe else [out]
+    gathered = [torch.empty((n * world, ncol), dtype=torch.float32, device=dev) for _ in range(2)] if (pipe and rank == 0) else [None, None]
+    works = [None, None]
+    count = [0]
 
     def step():
         if args.workload == "icpc":
-            ldsp.icpc_run(wf, params, ctx, out=out)
-            if world > 1:
-                ldist.gather_table(out, n * world, dst=0, out=gathered)
+            k = count[0] % len(outs)
+            count[0] += 1
+            if works[k] is not None:
+                works[k].wait()                      # the gather that read outs[k] two batches ago
+                works[k] = None
+            ldsp.icpc_run(wf, params, ctx, out=outs[k])
+            if pipe:
+                _, works[k] = ldist.gather_table(outs[k], n * world, dst=0, out=gathered[k], async_op=True)
         else:
             ldsp.icpc_pz_trap_run(wf, params, ctx, out=out)
 
     def fence():
+        for k in range(2):
+            if works[k] is not None:
+                works[k].wait()                      # every gather issued so far is inside the timed region
+                works[k] = None
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -226,7 +243,7 @@ def main():
                                     else f"BASELINE config 2: {n} x {L} f32, pole-zero + trapezoid"),
                        "traces_per_gpu": n, "samples": L, "dt_ns": dt,
                        "dsp_config": "reference test/test_dsp_icpc.jl:50-161", "tau_us": 500,
-                       "gather": "rccl gather of [n,48] f32 to rank 0" if world > 1 else "none"},
+                       "gather": "rccl gather of [n,48] f32 to rank 0, overlapped with the next batch's kernel (double-buffered)" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": dom_kernel,

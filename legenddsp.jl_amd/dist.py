@@ -5,7 +5,8 @@ combines data across traces.  One process per GPU; rank r owns the contiguous
 trace range `shard_range(n, world, r)`, runs the fused kernel on it, and the
 only collective is ONE gather of the [n_r, 48] float32 output shards to rank 0
 (`torch.distributed` backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
-the CPU tests).  No data-path collective.
+the CPU tests).  No data-path collective.  The gather of batch k can run (async, on the collective's stream) while the
+kernel of batch k+1 computes: `gather_table(..., async_op=True)` with double-buffered tables, as bench.py does.
 """
 from __future__ import annotations
 
@@ -20,14 +21,17 @@ def shard_range(n: int, world: int, rank: int):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def gather_table(tab: torch.Tensor, n_total: int, dst: int = 0, group=None, out: torch.Tensor = None):
+def gather_table(tab: torch.Tensor, n_total: int, dst: int = 0, group=None, out: torch.Tensor = None, async_op: bool = False):
     """Gather the per-rank [n_r, C] shards into the [n_total, C] table on `dst`
     (row order = global trace index).  Returns the table on dst, None elsewhere.
 
     Shards may differ by one row; they are padded to the largest shard so that a
     single fixed-size gather moves everything (one collective, direct peer links).
     `out` (dst only, optional): a preallocated [world * ceil(n_total / world), C] buffer that receives the
-    shards in place — with equal shards the result is a view of it (no allocation, no copy)."""
+    shards in place — with equal shards the result is a view of it (no allocation, no copy).
+    `async_op=True` (equal shards only): returns `(table_or_None, work)` at once; the transfer runs on the collective's own
+    stream — concurrently with whatever the caller launches next on the compute stream — and `work.wait()` orders the compute
+    stream behind it.  The caller must not overwrite `tab` (nor read the table) before that."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return tab
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -42,6 +46,11 @@ def gather_table(tab: torch.Tensor, n_total: int, dst: int = 0, group=None, out:
         if out is None or out.shape != (world * nmax, C) or out.dtype != tab.dtype or out.device != tab.device:
             out = torch.empty((world * nmax, C), dtype=tab.dtype, device=tab.device)
         bufs = list(out.split(nmax, dim=0))   # contiguous row blocks of the result: the gather writes the table itself
+    if async_op:
+        if n_total != world * nmax:
+            raise ValueError("async gather needs equal shards")
+        work = dist.gather(send.contiguous(), bufs, dst=dst, group=group, async_op=True)
+        return (out if rank == dst else None), work
     dist.gather(send.contiguous(), bufs, dst=dst, group=group)
     if rank != dst:
         return None
