@@ -1438,10 +1438,12 @@ trap_grid_kernel(const float* __restrict__ wf, const TrapGridDev* __restrict__ P
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const TrapGridDev& P = *Pp;
   const int L = FULL ? Lp : P.L, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  // ONE trace-sized array: it holds y while the t50 crossing is looked up (pick_mode 1), then T.  35 KB per workgroup at
+  // L = 8192: four workgroups per CU keep four traces' loads in flight (with separate y and T arrays: two).
   float* T = reinterpret_cast<float*>(smem_raw);                                   // [Lp+64]
-  float* Y = T + Lp + 64;                                                           // [Lp]
-  uint32_t* bm = reinterpret_cast<uint32_t*>(Y + Lp);                               // [NWORDS]
-  double* part = reinterpret_cast<double*>(smem_raw + (size_t)(2 * Lp + 64 + NWORDS) * 4);   // [2][R*NW]
+  float* Y = T;
+  uint32_t* bm = reinterpret_cast<uint32_t*>(T + Lp + 64);                          // [NWORDS]
+  double* part = reinterpret_cast<double*>(smem_raw + (size_t)(Lp + 64 + NWORDS) * 4);   // [2][R*NW]
   double* wsum = part + 2 * R * NW;                                                 // [NW]
   float* estB = reinterpret_cast<float*>(wsum + NW);                                // [EST_TBL]
   uint32_t* slot = reinterpret_cast<uint32_t*>(estB + EST_TBL);                     // [4] max(y), first crossing, count
@@ -1449,7 +1451,6 @@ trap_grid_kernel(const float* __restrict__ wf, const TrapGridDev* __restrict__ P
   float x[R][4];
   load_trace_s4<NT, R, FULL>(w, L, tid, x);
   for (int i = tid; i < EST_TBL; i += NT) estB[i] = P.est.B[i];
-  if (tid < 64) T[Lp + tid] = 0.f;
   if (tid == 0) { slot[0] = 0u; slot[1] = 0x7fffffffu; slot[2] = 0u; }
   // baseline mean exactly as icpc_kernel forms it
   const float pv_bl = w[P.bl.from];
@@ -1485,22 +1486,12 @@ trap_grid_kernel(const float* __restrict__ wf, const TrapGridDev* __restrict__ P
       ymax = vmax(ymax, (i0 + e < L) ? x[r][e] : -INFINITY);
     }
     tot[r] = (x[r][0] + x[r][1]) + (x[r][2] + x[r][3]);
-    *reinterpret_cast<float4*>(&Y[i0]) = make_float4(x[r][0], x[r][1], x[r][2], x[r][3]);
+    if (P.pick_mode == 1) *reinterpret_cast<float4*>(&Y[i0]) = make_float4(x[r][0], x[r][1], x[r][2], x[r][3]);
   }
   ymax = wave_max_all(ymax);
   if (lane == 0) atomicMax(&slot[0], ford(ymax));
   double tot_all;
-  s4_exscan_sum<NT, R>(tot, off, part + R * NW, &tot_all);   // barrier inside: Y and the maximum are published
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    double run = off[r];
-    float4 t;
-    float* pt = &t.x;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { pt[e] = (float)run; run += (double)x[r][e]; }
-    *reinterpret_cast<float4*>(&T[4 * (tid + NT * r)]) = t;
-  }
-  if (tid == 0) T[Lp] = (float)tot_all;
+  s4_exscan_sum<NT, R>(tot, off, part + R * NW, &tot_all);   // barrier inside: y (pick_mode 1) and the maximum are published
   // pick-off position (samples, int + frac)
   Pos base;
   base.ip = P.pick_ip; base.fp = P.pick_fp;
@@ -1527,9 +1518,20 @@ trap_grid_kernel(const float* __restrict__ wf, const TrapGridDev* __restrict__ P
       base.ip = 0; base.fp = -P.t_first / P.dt;
       base = pos_norm(base);
     }
-  } else {
-    __syncthreads();
+    __syncthreads();       // every read of y is done: the array becomes T
   }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double run = off[r];
+    float4 t;
+    float* pt = &t.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pt[e] = (float)run; run += (double)x[r][e]; }
+    *reinterpret_cast<float4*>(&T[4 * (tid + NT * r)]) = t;
+  }
+  if (tid == 0) T[Lp] = (float)tot_all;
+  if (tid < 63) T[Lp + 1 + tid] = 0.f;
+  __syncthreads();
   for (int g = wave; g < P.G; g += NW) {
     const TrapDev tr = P.trap[g];
     Pos p = (P.pick_mode == 1) ? pos_add(base, P.offs[g]) : base;
@@ -1542,7 +1544,7 @@ trap_grid_kernel(const float* __restrict__ wf, const TrapGridDev* __restrict__ P
 template <int NT, int R, bool FULL>
 static hipError_t launch_grid_t(const float* wf, int64_t n, const TrapGridDev* dP, float* out, hipStream_t st) {
   constexpr int NW = NT / 64, Lp = 16 * NT;
-  const size_t smem = (size_t)(2 * Lp + 64 + Lp / 32) * 4 + (2 * R * NW + NW) * 8 + EST_TBL * 4 + 32;
+  const size_t smem = (size_t)(Lp + 64 + Lp / 32) * 4 + (2 * R * NW + NW) * 8 + EST_TBL * 4 + 32;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trap_grid_kernel<NT, R, FULL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
