@@ -1763,11 +1763,13 @@ sg_grid_kernel(const float* __restrict__ wf, const SgGridDev* __restrict__ Pp, f
   double* wsum = part + 2 * R * NW;                                                 // [3][NW]
   float* estB = reinterpret_cast<float*>(wsum + 3 * NW);                            // [EST_TBL]
   uint32_t* slot = reinterpret_cast<uint32_t*>(estB + EST_TBL);                     // [4]
+  unsigned long long* vi = reinterpret_cast<unsigned long long*>(slot + 8);         // [LDSP_MAX_GRID] arg-max per window length
   const float* w = wf + (size_t)blockIdx.x * (size_t)L;
   float x[R][4];
   load_trace_s4<NT, R, FULL>(w, L, tid, x);
   for (int i = tid; i < EST_TBL; i += NT) estB[i] = P.est.B[i];
   if (tid < 64) { T[Lp + tid] = 0.f; Y[Lp + tid] = 0.f; }
+  if (tid < LDSP_MAX_GRID) vi[tid] = 0ull;
   if (tid == 0) { slot[0] = 0u; slot[1] = 0x7fffffffu; slot[2] = 0u; }
   const float pv_bl = w[P.bl.from];
   WinAccF bl = {0, 0, 0};
@@ -1859,19 +1861,43 @@ sg_grid_kernel(const float* __restrict__ wf, const SgGridDev* __restrict__ Pp, f
     const float e = estimate(P.est, estB, p, L - tr.flen + 1, [&](int i) { return trap_at(T, i, tr); });
     if (lane == 0 && energy) energy[blockIdx.x] = e;
   }
+  // SG window-length scan: every wave works on every window length (thread <-> output sample of the current window, four
+  // independent multiply-add chains per output so that the LDS reads of a tap group are in flight together); the arg-max of a
+  // window length is combined through an LDS slot, its parabola refinement is done by one wave per window length.
+  auto sg_at = [&](const float* c, int np, int k) {
+    const float* yp = &Y[k];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    for (; i + 4 <= np; i += 4) {
+      a0 = fmaf(c[i], yp[i], a0); a1 = fmaf(c[i + 1], yp[i + 1], a1);
+      a2 = fmaf(c[i + 2], yp[i + 2], a2); a3 = fmaf(c[i + 3], yp[i + 3], a3);
+    }
+    for (; i < np; ++i) a0 = fmaf(c[i], yp[i], a0);
+    return (a0 + a1) + (a2 + a3);
+  };
+  for (int g = 0; g < P.W; ++g) {
+    const int np = P.np[g], from = P.from[g], until = P.until[g];
+    const float* c = P.c[g];
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int k = from + tid; k <= until; k += NT) {
+      const float v = sg_at(c, np, k);
+      if (v > bv) { bv = v; bi = k; }
+    }
+    if (__ballot(bi != 0x7fffffff) != 0ull) {   // wave-uniform: this wave holds samples of the window
+      const unsigned long long best = wave_max_u64(pack_vi(bv, bi));
+      if (lane == 0) atomicMax(&vi[g], best);
+    }
+  }
+  __syncthreads();
   for (int g = wave; g < P.W; g += NW) {
     const int np = P.np[g], from = P.from[g], until = P.until[g];
     const float* c = P.c[g];
-    auto sg_at = [&](int k) { float a = 0.f; for (int i = 0; i < np; ++i) a = fmaf(c[i], Y[k + i], a); return a; };
-    float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int k = from + lane; k <= until; k += 64) {
-      const float v = sg_at(k);
-      if (v > bv) { bv = v; bi = k; }
-    }
-    unsigned long long best = wave_max_u64(pack_vi(bv, bi));
     float v; int i;
-    unpack_vi(best, &v, &i);
-    if (i > from && i < until) v = extrema3points(sg_at(i - 1), sg_at(i), sg_at(i + 1));   // get_wvf_maximum (src/interpolation.jl:30-46)
+    unpack_vi(vi[g], &v, &i);
+    if (i > from && i < until) {   // get_wvf_maximum (src/interpolation.jl:30-46): lanes 0..2 evaluate the three samples
+      const float e = (lane < 3) ? sg_at(c, np, i - 1 + lane) : 0.f;
+      v = extrema3points(__shfl(e, 0), __shfl(e, 1), __shfl(e, 2));
+    }
     if (lane == 0 && amax) amax[(size_t)g * (size_t)n + blockIdx.x] = v;
   }
 }
@@ -1880,7 +1906,7 @@ template <int NT, int R, bool FULL>
 static hipError_t launch_sg_grid_t(const float* wf, int64_t n, const SgGridDev* dP, float* amax, float* energy, float* t50, float* blm, float* bls,
                                    hipStream_t st) {
   constexpr int NW = NT / 64, Lp = 16 * NT;
-  const size_t smem = (size_t)(2 * Lp + 128 + Lp / 32) * 4 + (2 * R * NW + 3 * NW) * 8 + EST_TBL * 4 + 32;
+  const size_t smem = (size_t)(2 * Lp + 128 + Lp / 32) * 4 + (2 * R * NW + 3 * NW) * 8 + EST_TBL * 4 + 32 + LDSP_MAX_GRID * 8;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sg_grid_kernel<NT, R, FULL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;

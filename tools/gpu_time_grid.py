@@ -16,3 +16,12 @@ for name, fn in (("dsp_trap_rt_optimization", lambda: ldsp.dsp_trap_rt_optimizat
     G = out.shape[0]
     b = n * (4 * L + 4 * G)
     print(f"{name}: grid {G} x {n} traces: {ms:.3f} ms -> {n/ms*1e3/1e6:.1f} Mwf/s ({n*G/ms*1e3/1e9:.2f} G filter-evaluations/s), {b/ms*1e3/1e12:.2f} TB/s = {b/ms*1e3/8e12*100:.0f}% of 8 TB/s")
+import dataclasses
+cfg2 = dataclasses.replace(cfg, a_grid_wl_sg=ldsp.StepRange(80 * ldsp.ns, 32 * ldsp.ns, 350 * ldsp.ns))   # from 5 points up (a cubic needs 4)
+pf = {"trap": {"rt": 8 * ldsp.us, "ft": 3 * ldsp.us}}
+fn = lambda: ldsp.dsp_sg_optimization(wvfs, cfg2, 500 * ldsp.us, pf, ctx=ctx)
+out = fn(); torch.cuda.synchronize()
+ms = min((fn(), ctx.last_kernel_ms())[1] for _ in range(3))
+W = out["aoe"].shape[0]
+b = n * (4 * L + 4 * (W + 4))
+print(f"dsp_sg_optimization: {W} window lengths x {n} traces: {ms:.3f} ms -> {n/ms*1e3/1e6:.1f} Mwf/s, {b/ms*1e3/1e12:.2f} TB/s = {b/ms*1e3/8e12*100:.0f}% of 8 TB/s")
