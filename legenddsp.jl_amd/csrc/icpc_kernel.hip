@@ -1073,25 +1073,14 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       const float *tia = tb + t0i.n1, *tib = tb + t0i.n1 + t0i.g, *tic = tb + t0i.flen;
       const float rr0 = t0.rr, rri = t0i.rr;
       const float thr0 = P.t0_thr * t0.navg, thr0i = -P.t0_thr * t0i.navg;
-#pragma unroll
-      for (int m = 0; m < SP; ++m) {
-        const int k = tid + NT * m;
-        float yv = yb[NT * m];
-        if (!FULL && NT * (m + 1) > L) yv = (k < L) ? yv : -INFINITY;
+      // ballots of one row and the stores of the non-zero ones.  The mask words were zeroed in phase 2: all-zero ballots
+      // (most rows of the t0 masks, the baseline rows of the y masks) are not stored.  thr_tx ascends, so bq[0] covers bq[1..4].
+      auto emit = [&](int m, float yv, float o0, float o0i) {
         unsigned long long bq[7];
 #pragma unroll
         for (int q = 0; q < 5; ++q) bq[q] = __ballot(yv >= thr_tx[q]);
-        const float Tk = tb[NT * m];
-        float o0 = NAN, o0i = NAN;   // NaN: both comparisons false for rows/lanes outside the output range
-        if (NT * (m + 1) <= nout_t0) o0 = traw(t0a, t0b, t0c, rr0, Tk, m);
-        else if (NT * m < nout_t0) { o0 = traw(t0a, t0b, t0c, rr0, Tk, m); o0 = (k < nout_t0) ? o0 : NAN; }
-        if (inv_same) o0i = o0;
-        else if (NT * (m + 1) <= nout_t0i) o0i = traw(tia, tib, tic, rri, Tk, m);
-        else if (NT * m < nout_t0i) { o0i = traw(tia, tib, tic, rri, Tk, m); o0i = (k < nout_t0i) ? o0i : NAN; }
         bq[M_T0] = __ballot(o0 >= thr0);
         bq[M_T0INV] = __ballot(o0i <= thr0i);   // -trap >= thr
-        // the mask words were zeroed in phase 2: all-zero ballots (most rows of the t0 masks, the
-        // baseline rows of the y masks) are not stored.  thr_tx ascends, so bq[0] covers bq[1..4].
         if (lane == 0) {
           const int wb = (NT >> 5) * m + 2 * wave;
           if (bq[0] | (e_max <= 0.f ? ~0ull : 0ull)) {
@@ -1100,6 +1089,44 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
           }
           if (bq[M_T0]) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0 * NWORDS + wb]) = bq[M_T0];
           if (bq[M_T0INV]) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0INV * NWORDS + wb]) = bq[M_T0INV];
+        }
+      };
+      static_assert(SP % 4 == 0, "row groups");
+      const int nout_grp = inv_same ? nout_t0 : min(nout_t0, nout_t0i);
+#pragma unroll
+      for (int m0 = 0; m0 < SP; m0 += 4) {
+        if (NT * (m0 + 4) <= nout_grp) {
+          // four rows wholly inside the trace and both output ranges: all their reads go out before the first comparison
+          // (compiler fence), the LDS latency is paid once per group
+          float yv[4], tk[4], ra[4], rb[4], rc[4], ia[4], ib[4], ic[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            yv[q] = yb[NT * (m0 + q)]; tk[q] = tb[NT * (m0 + q)];
+            ra[q] = t0a[NT * (m0 + q)]; rb[q] = t0b[NT * (m0 + q)]; rc[q] = t0c[NT * (m0 + q)];
+            if (!inv_same) { ia[q] = tia[NT * (m0 + q)]; ib[q] = tib[NT * (m0 + q)]; ic[q] = tic[NT * (m0 + q)]; }
+          }
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float o0 = fmaf(rc[q] - rb[q], rr0, -(ra[q] - tk[q]));
+            const float o0i = inv_same ? o0 : fmaf(ic[q] - ib[q], rri, -(ia[q] - tk[q]));
+            emit(m0 + q, yv[q], o0, o0i);
+          }
+          continue;
+        }
+#pragma unroll
+        for (int m = m0; m < m0 + 4; ++m) {
+          const int k = tid + NT * m;
+          float yv = yb[NT * m];
+          if (!FULL && NT * (m + 1) > L) yv = (k < L) ? yv : -INFINITY;
+          const float Tk = tb[NT * m];
+          float o0 = NAN, o0i = NAN;   // NaN: both comparisons false for rows/lanes outside the output range
+          if (NT * (m + 1) <= nout_t0) o0 = traw(t0a, t0b, t0c, rr0, Tk, m);
+          else if (NT * m < nout_t0) { o0 = traw(t0a, t0b, t0c, rr0, Tk, m); o0 = (k < nout_t0) ? o0 : NAN; }
+          if (inv_same) o0i = o0;
+          else if (NT * (m + 1) <= nout_t0i) o0i = traw(tia, tib, tic, rri, Tk, m);
+          else if (NT * m < nout_t0i) { o0i = traw(tia, tib, tic, rri, Tk, m); o0i = (k < nout_t0i) ? o0i : NAN; }
+          emit(m, yv, o0, o0i);
         }
       }
     }
@@ -1115,8 +1142,33 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       // inside an output range take the unmasked branch (scalar test); the one straddling pair
       // of each trapezoid runs row by row with lane masks.
       static_assert(SP % 2 == 0, "row pairs");
+      const int nout_all = min(min(nout_f0, nout_f1), min(nout_f2, nout_opt));
 #pragma unroll
       for (int m = 0; m < SP; m += 2) {
+        if (NT * (m + 2) <= nout_all) {
+          // pair wholly inside every output range (most pairs): ALL 26 reads are issued before the arithmetic starts
+          // (compiler fence), so the LDS latency is paid once per pair instead of once per read or two
+          float a[4][2], b[4][2], c[4][2], t[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            t[q] = tb[NT * (m + q)];
+            a[0][q] = f0a[NT * (m + q)]; b[0][q] = f0b[NT * (m + q)]; c[0][q] = f0c[NT * (m + q)];
+            a[1][q] = f1a[NT * (m + q)]; b[1][q] = f1b[NT * (m + q)]; c[1][q] = f1c[NT * (m + q)];
+            a[2][q] = f2a[NT * (m + q)]; b[2][q] = f2b[NT * (m + q)]; c[2][q] = f2c[NT * (m + q)];
+            a[3][q] = foa[NT * (m + q)]; b[3][q] = fob[NT * (m + q)]; c[3][q] = foc[NT * (m + q)];
+          }
+          asm volatile("" ::: "memory");
+          auto tv = [&](int j, float rr, int q) { return fmaf(c[j][q] - b[j][q], rr, -(a[j][q] - t[q])); };
+          const float o00 = tv(0, rr0, 0), o01 = tv(0, rr0, 1);
+          mx0 = vmax3(mx0, o00, o01); mn0 = vmin3(mn0, o00, o01);
+          mx1 = vmax3(mx1, tv(1, rr1, 0), tv(1, rr1, 1));
+          const float o20 = tv(2, rr2, 0), o21 = tv(2, rr2, 1);
+          mx2 = vmax3(mx2, o20, o21); mn2 = vmin3(mn2, o20, o21);
+          const float oo0 = tv(3, rro, 0), oo1 = tv(3, rro, 1);
+          if (oo0 > bo_v) { bo_v = oo0; bo_i = tid + NT * m; }
+          if (oo1 > bo_v) { bo_v = oo1; bo_i = tid + NT * (m + 1); }
+          continue;
+        }
         const float Tk0 = tb[NT * m], Tk1 = tb[NT * (m + 1)];
         auto row = [&](int mm) { return mm == m ? Tk0 : Tk1; };
         if (NT * (m + 2) <= nout_f0) {
