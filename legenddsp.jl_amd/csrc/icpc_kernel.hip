@@ -1801,17 +1801,19 @@ hipError_t launch_fir_grid(const float* wf, int64_t n, int NT, bool full, const 
 // slope, pole-zero, T, t50), the trapezoid energy at t50 + rt + ft/2, then one wave per SG window length: the
 // derivative filter only inside the current window (lane-strided), first-occurrence arg-max, parabola vertex.
 template <int NT, int R, bool FULL>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, 8)   // <= 64 VGPRs: with the single trace-sized LDS array, four 512-thread workgroups per CU
 sg_grid_kernel(const float* __restrict__ wf, const SgGridDev* __restrict__ Pp, float* __restrict__ amax, float* __restrict__ energy,
                float* __restrict__ t50_us, float* __restrict__ o_blmean, float* __restrict__ o_blslope, int64_t n) {
   constexpr int NW = NT / 64, SP = 4 * R, Lp = NT * SP, NWORDS = Lp / 32;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const SgGridDev& P = *Pp;
   const int L = FULL ? Lp : P.L, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  // ONE trace-sized array: y for the t50 crossing and the window-length scan, then T for the trapezoid energy (36 KB per
+  // workgroup at L = 8192: four workgroups per CU instead of two)
   float* T = reinterpret_cast<float*>(smem_raw);                                   // [Lp+64]
-  float* Y = T + Lp + 64;                                                           // [Lp+64]
-  uint32_t* bm = reinterpret_cast<uint32_t*>(Y + Lp + 64);                          // [NWORDS]
-  double* part = reinterpret_cast<double*>(smem_raw + (size_t)(2 * Lp + 128 + NWORDS) * 4);   // [2][R*NW]
+  float* Y = T;
+  uint32_t* bm = reinterpret_cast<uint32_t*>(T + Lp + 64);                          // [NWORDS]
+  double* part = reinterpret_cast<double*>(smem_raw + (size_t)(Lp + 64 + NWORDS) * 4);   // [2][R*NW]
   double* wsum = part + 2 * R * NW;                                                 // [3][NW]
   float* estB = reinterpret_cast<float*>(wsum + 3 * NW);                            // [EST_TBL]
   uint32_t* slot = reinterpret_cast<uint32_t*>(estB + EST_TBL);                     // [4]
@@ -1820,7 +1822,7 @@ sg_grid_kernel(const float* __restrict__ wf, const SgGridDev* __restrict__ Pp, f
   float x[R][4];
   load_trace_s4<NT, R, FULL>(w, L, tid, x);
   for (int i = tid; i < EST_TBL; i += NT) estB[i] = P.est.B[i];
-  if (tid < 64) { T[Lp + tid] = 0.f; Y[Lp + tid] = 0.f; }
+  if (tid < 64) Y[Lp + tid] = 0.f;
   if (tid < LDSP_MAX_GRID) vi[tid] = 0ull;
   if (tid == 0) { slot[0] = 0u; slot[1] = 0x7fffffffu; slot[2] = 0u; }
   const float pv_bl = w[P.bl.from];
@@ -1868,17 +1870,7 @@ sg_grid_kernel(const float* __restrict__ wf, const SgGridDev* __restrict__ Pp, f
   ymax = wave_max_all(ymax);
   if (lane == 0) atomicMax(&slot[0], ford(ymax));
   double tot_all;
-  s4_exscan_sum<NT, R>(tot, off, part + R * NW, &tot_all);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    double run = off[r];
-    float4 t;
-    float* pt = &t.x;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { pt[e] = (float)run; run += (double)x[r][e]; }
-    *reinterpret_cast<float4*>(&T[4 * (tid + NT * r)]) = t;
-  }
-  if (tid == 0) T[Lp] = (float)tot_all;
+  s4_exscan_sum<NT, R>(tot, off, part + R * NW, &tot_all);   // barrier inside: y and the maximum are published
   // t50 = get_threshold(wvfs, 0.5 * maximum; mintot)   :421
   const float thr = 0.5f * ford_inv(slot[0]);
 #pragma unroll
@@ -1906,13 +1898,6 @@ sg_grid_kernel(const float* __restrict__ wf, const SgGridDev* __restrict__ Pp, f
     base = pos_norm(base);
   }
   if (tid == 0 && t50_us) t50_us[blockIdx.x] = t50;
-  if (wave == NW - 1) {   // energy: the last wave (the grid loop below starts at wave 0)
-    Pos p = pos_add(base, P.trap_off);
-    p.ip -= (P.trap.flen - 1);
-    const TrapDev tr = P.trap;
-    const float e = estimate(P.est, estB, p, L - tr.flen + 1, [&](int i) { return trap_at(T, i, tr); });
-    if (lane == 0 && energy) energy[blockIdx.x] = e;
-  }
   // SG window-length scan: every wave works on every window length (thread <-> output sample of the current window, four
   // independent multiply-add chains per output so that the LDS reads of a tap group are in flight together); the arg-max of a
   // window length is combined through an LDS slot, its parabola refinement is done by one wave per window length.
@@ -1952,13 +1937,32 @@ sg_grid_kernel(const float* __restrict__ wf, const SgGridDev* __restrict__ Pp, f
     }
     if (lane == 0 && amax) amax[(size_t)g * (size_t)n + blockIdx.x] = v;
   }
+  __syncthreads();   // every read of y is done: the array becomes T
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double run = off[r];
+    float4 t;
+    float* pt = &t.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pt[e] = (float)run; run += (double)x[r][e]; }
+    *reinterpret_cast<float4*>(&T[4 * (tid + NT * r)]) = t;
+  }
+  if (tid == 0) T[Lp] = (float)tot_all;
+  __syncthreads();
+  if (wave == 0) {   // energy: trapezoid output at t50 + rt + ft/2 through the estimator
+    Pos p = pos_add(base, P.trap_off);
+    p.ip -= (P.trap.flen - 1);
+    const TrapDev tr = P.trap;
+    const float e = estimate(P.est, estB, p, L - tr.flen + 1, [&](int i) { return trap_at(T, i, tr); });
+    if (lane == 0 && energy) energy[blockIdx.x] = e;
+  }
 }
 
 template <int NT, int R, bool FULL>
 static hipError_t launch_sg_grid_t(const float* wf, int64_t n, const SgGridDev* dP, float* amax, float* energy, float* t50, float* blm, float* bls,
                                    hipStream_t st) {
   constexpr int NW = NT / 64, Lp = 16 * NT;
-  const size_t smem = (size_t)(2 * Lp + 128 + Lp / 32) * 4 + (2 * R * NW + 3 * NW) * 8 + EST_TBL * 4 + 32 + LDSP_MAX_GRID * 8;
+  const size_t smem = (size_t)(Lp + 64 + Lp / 32) * 4 + (2 * R * NW + 3 * NW) * 8 + EST_TBL * 4 + 32 + LDSP_MAX_GRID * 8;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sg_grid_kernel<NT, R, FULL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
