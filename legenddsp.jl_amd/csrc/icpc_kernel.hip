@@ -1619,7 +1619,7 @@ hipError_t launch_trap_grid(const float* wf, int64_t n, int NT, bool full, const
 // just the npts filter outputs under the SignalEstimator window: lane l <-> output i0+l, consecutive lanes on
 // consecutive LDS words, one scalar tap load per 16 taps.
 template <int NT, int R, bool FULL>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, 6)   // <= 80 VGPRs: three 512-thread workgroups per CU (64 VGPRs would spill the accumulators)
 fir_grid_kernel(const float* __restrict__ wf, const FirGridDev* __restrict__ Pp, float* __restrict__ out, int64_t n) {
   constexpr int NW = NT / 64, SP = 4 * R, Lp = NT * SP, NWORDS = Lp / 32;
   extern __shared__ __align__(16) unsigned char smem_raw[];
