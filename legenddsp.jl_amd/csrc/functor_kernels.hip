@@ -212,9 +212,16 @@ __global__ void __launch_bounds__(256) k_qc_features(const float* __restrict__ x
     mean = (float)((double)pv + (red[0] + red[1] + red[2] + red[3]) / (double)(bl_until - bl_from + 1));
   }
   const float c = 0.70710678118654752f;   // inv(sqrt(T(2)))  src/haar_filter.jl:27
-  for (int i = tid; i < n1; i += 256) {
-    const int s = 2 * i;
-    A[i] = ((xr[s] - mean) + (xr[min(s + 1, L - 1)] - mean)) * c;
+  if ((L & 3) == 0) {   // rows 16-byte aligned: one dwordx4 load feeds two outputs, the loads of a thread are independent
+    for (int j = tid; j < (L >> 2); j += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + 4 * j);
+      *reinterpret_cast<float2*>(&A[2 * j]) = make_float2(((v.x - mean) + (v.y - mean)) * c, ((v.z - mean) + (v.w - mean)) * c);
+    }
+  } else {
+    for (int i = tid; i < n1; i += 256) {
+      const int s = 2 * i;
+      A[i] = ((xr[s] - mean) + (xr[min(s + 1, L - 1)] - mean)) * c;
+    }
   }
   __syncthreads();
   float *src = A, *dst = B;
