@@ -4,33 +4,81 @@
 A "step" is one pass of the fused dsp_icpc chain (reference src/dsp_icpc.jl:62-230,
 full chain incl. CUSP/ZAC + extremestats + Intersect family = BASELINE config 3)
 over one batch of synthetic HPGe traces that is already resident in HBM.
-  N = 1 : 1 M x 8192-sample float32 traces on one GPU (config 3).
-  N > 1 : each rank owns its own 1 M-trace shard (weak scaling), runs the same
-          kernel and the [n,48] output shards are gathered to rank 0 with one
-          RCCL gather per batch inside the timed region (config 4 shape); the
-          gather of batch k overlaps the kernel of batch k+1 (double-buffered
-          tables, all gathers complete before the closing barrier).
-Prints ONE JSON line (rank 0).  `--workload pz_trap` times BASELINE config 2
-(blmean -> shift -> InvCR -> Trap(10us,4us) -> max) instead; `--workload sipm` times BASELINE
-config 5's shape (fused dsp_sipm, 16384-sample traces, 625 k per GPU by default).
+  N = 1 : 1 M x 8192-sample float32 traces on one GPU (config 3).  The default run also times, after the
+          headline, BASELINE config 2 (pole-zero + trapezoid sub-chain, same batch) and config 5's single-GPU
+          shard (fused dsp_sipm, 625 k x 16384) and reports them under "secondary" (`--no-secondary` skips them).
+  N > 1 : each rank owns its own shard (weak scaling: 1.25 M traces per rank = config 4's 10 M over 8), runs
+          the same kernel and the [n,48] output shards are gathered to rank 0 with one RCCL gather per batch
+          inside the timed region; the gather of batch k overlaps the kernel of batch k+1 (double-buffered
+          tables, all gathers complete before the closing barrier).  `--workload sipm` (config 5: 625 k x 16384
+          per rank) gathers the 20 scalar columns AND the 12 ragged trigger columns (counts -> exclusive scan on
+          the root -> payload with per-peer sizes, `dist.gather_ragged`).
+Launch: `python bench.py --gpus N ...` starts its own N ranks (one fresh process per GPU; the parent touches
+neither torch nor the GPU and relays the children's exit status); under `python -m torch.distributed.run` (RANK /
+WORLD_SIZE already set) it is one of the ranks.  Prints ONE JSON line (rank 0).
+`--dry-run` rehearses the launch + gather plumbing on CPU (gloo, kernels replaced by table fills, no number of
+merit): what the CPU tests run.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import legenddsp_jl_amd as ldsp  # noqa: E402
-from legenddsp_jl_amd import dist as ldist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md chip table)
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=None, help="traces per GPU (default: icpc 1 M at N = 1, 1.25 M at N > 1; sipm 625 k)")
+    ap.add_argument("--L", type=int, default=None, help="samples per trace (default 8192; 16384 for sipm)")
+    ap.add_argument("--workload", choices=["icpc", "pz_trap", "sipm"], default="icpc")
+    ap.add_argument("--cpu-sample", type=int, default=65536, help="traces timed on the host cores (0 = skip); ~10 s on 16 cores")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: do not append the config 2 / config 5 lines")
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launcher and the gathers (gloo; no kernels, no GPU)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no rank environment -> N child processes, one per GPU
+
+def launch_ranks(args, argv):
+    """Start N fresh rank processes of this script and wait for them.  The parent imports neither torch nor the
+    package (it must not initialise the GPU); it relays a non-zero exit status and ends the other ranks when one dies."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    alive = set(range(len(procs)))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:          # a dead rank leaves the others in a collective for ever: end exactly those processes
+                    procs[q].terminate()
+        if alive:
+            time.sleep(0.2)
+    return rc if rc >= 0 else 1
+
+
+# ------------------------------------------------------------------------------------------------------------------
 
 def measured_traffic(kernel, n, L):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this same command
@@ -43,184 +91,183 @@ def measured_traffic(kernel, n, L):
                 rec = json.load(f)
         except (OSError, ValueError):
             continue
-        if rec.get("n_traces") != n or rec.get("L") != L:
-            continue
-        for name, v in rec.get("kernels", {}).items():
-            if name.startswith("ldsp::" + kernel + "<"):
-                return {"bytes": v["hbm_bytes_per_launch_corrected"], "source": os.path.relpath(path, ROOT)}
+        recs = rec if isinstance(rec, list) else [rec]
+        for rec in recs:
+            if rec.get("n_traces") != n or rec.get("L") != L:
+                continue
+            for name, v in rec.get("kernels", {}).items():
+                if name.startswith("ldsp::" + kernel + "<"):
+                    return {"bytes": v["hbm_bytes_per_launch_corrected"], "source": os.path.relpath(path, ROOT)}
     return None
 
 
-def bench_sipm(args, n, L, world, rank, dev):
-    """dsp_sipm (reference src/dsp_sipm.jl:47-158): weak scaling, each rank its own shard; the ragged trigger columns
-    stay on the rank that produced them (fixed-capacity slabs + counts), scalar columns are gathered to rank 0."""
-    params = ldsp.lower_sipm(ldsp.reference_test_sipm_config(), {"sg": {"wl": 200 * ldsp.ns}}, L, 0.0, 16.0)
-    wf = torch.empty((n, L), dtype=torch.float32, device=dev)
-    ldsp.synth.sipm_batch(n, L, device=dev, out=wf)
-    ctx = ldsp.Context(dev.index)
-    ctx.enable_timing(True)
-    bufs = ldsp.sipm_run(wf, params, ctx)      # allocates the output buffers once
+class Env:
+    """What a rank needs: world / rank, its device, torch.distributed started (N > 1)."""
 
-    def step():
-        ldsp.sipm_run(wf, params, ctx, out=bufs)
-        if world > 1:
-            ldist.gather_table(bufs[0].t().contiguous(), n * world, dst=0)
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dry = args.dry_run
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if self.dry:
+            self.dev = torch.device("cpu")
+        else:
+            self.dev = torch.device("cuda", self.local_rank)
+            torch.cuda.set_device(self.dev)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if self.dry:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)    # "nccl" is RCCL on ROCm
 
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+    def sync(self):
+        if not self.dry:
+            self.torch.cuda.synchronize(self.dev)
 
+    def fence(self):
+        self.sync()
+        if self.world > 1:
+            self.dist.barrier()
+            self.sync()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def timed(env, args, step, finish=lambda: None):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
     for _ in range(args.warmup):
         step()
-    fence()
+    finish()
+    env.fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kms = []
-    for _ in range(3):
-        ldsp.sipm_run(wf, params, ctx, out=bufs)
-        kms.append(ctx.last_kernel_ms())
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0:
-        kms = sum(kms) / len(kms)
-        elems = sum(int(bufs[1][g]["count"].clamp(max=ldsp._abi.LDSP_MAX_TRIG).sum()) for g in bufs[1]) * 4   # 4 ragged fields per group
-        bytes_per_trace = 4 * L + 4 * 20 + 8.0 * elems / n      # SURVEY 8(d), C5: measured ragged element count
-        achieved = n * bytes_per_trace / (kms * 1e-3) / 1e9
-        wps = n * world * args.steps / elapsed
-        res = {
-            "metric": "waveforms/s, fused dsp_sipm, 16384-sample f32", "value": wps, "unit": "waveforms/s",
-            "msamples_per_s": wps * L / 1e6, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 5 shape: dsp_sipm, 16384-sample f32 traces", "traces_per_gpu": n, "samples": L,
-                       "dt_ns": 16.0, "dsp_config": "reference test/test_dsp_sipm.jl:38-68 + sg.wl = 200 ns",
-                       "ragged_elements_per_trace": elems / n},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_sipm_s4", "kernel_ms": kms, "algorithmic_bytes_per_trace": bytes_per_trace},
-        }
-        print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+    finish()
+    env.fence()
+    return env.max_over_ranks(time.perf_counter() - t0)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=None, help="traces per GPU (default 1 M; 625 k for sipm)")
-    ap.add_argument("--L", type=int, default=None, help="samples per trace (default 8192; 16384 for sipm)")
-    ap.add_argument("--workload", choices=["icpc", "pz_trap", "sipm"], default="icpc")
-    ap.add_argument("--cpu-sample", type=int, default=65536, help="traces timed on the host cores (0 = skip); ~10 s on 16 cores")
-    args = ap.parse_args()
+def roofline(achieved_gbs, kernel, kernel_ms, bytes_per_trace, traffic):
+    r = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+         "traffic": None, "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_trace": bytes_per_trace}
+    if traffic:
+        r["traffic"] = traffic["bytes"]
+        r["traffic_source"] = traffic["source"]
+    return r
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
-        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
 
-    n = args.n if args.n is not None else (625_000 if args.workload == "sipm" else 1_000_000)
-    L = args.L if args.L is not None else (16384 if args.workload == "sipm" else 8192)
-    if args.workload == "sipm":
-        return bench_sipm(args, n, L, world, rank, dev)
-    dt = 16.0 * (8192 / L) if L < 8192 else 16.0  # 4096-sample plumbing config needs 32 ns (SURVEY §8)
-    cfg = ldsp.reference_test_icpc_config() if L >= 8192 else ldsp.plumbing_icpc_config_4096()
-    params = ldsp.lower_icpc(cfg, 500 * ldsp.us, {}, L, 0.0, dt)
+# ------------------------------------------------------------------------------------------------------------------
+# dsp_icpc (config 3 / 4) and the pole-zero + trapezoid sub-chain (config 2)
 
-    # synthetic input, generated directly in HBM (excluded from timing)
-    wf = torch.empty((n, L), dtype=torch.float32, device=dev)
-    ldsp.synth.hpge_batch(n, L, device=dev, out=wf, first_trace=rank * n)
-    ctx = ldsp.Context(dev.index)
-    ctx.enable_timing(True)
-    ncol = len(ldsp._abi.ICPC_COLS)
-    out = torch.empty((n, ncol), dtype=torch.float32, device=dev) if args.workload == "icpc" else \
+def bench_icpc(env, args, n, L, workload, wf=None):
+    torch = env.torch
+    from legenddsp_jl_amd import dist as ldist
+    world, rank, dev = env.world, env.rank, env.dev
+    ncol = 48
+    if not env.dry:
+        import legenddsp_jl_amd as ldsp
+        dt = 16.0 * (8192 / L) if L < 8192 else 16.0  # 4096-sample plumbing config needs 32 ns (SURVEY §8)
+        cfg = ldsp.reference_test_icpc_config() if L >= 8192 else ldsp.plumbing_icpc_config_4096()
+        params = ldsp.lower_icpc(cfg, 500 * ldsp.us, {}, L, 0.0, dt)
+        if wf is None:   # synthetic input, generated directly in HBM (excluded from timing)
+            wf = torch.empty((n, L), dtype=torch.float32, device=dev)
+            ldsp.synth.hpge_batch(n, L, device=dev, out=wf, first_trace=rank * n)
+        ctx = ldsp.Context(dev.index)
+        ctx.enable_timing(True)
+        ncol = len(ldsp._abi.ICPC_COLS)
+    else:
+        dt = 16.0
+    out = torch.empty((n, ncol), dtype=torch.float32, device=dev) if workload == "icpc" else \
         torch.empty((2, n), dtype=torch.float32, device=dev)
+
+    def kernel(dst, k):
+        if env.dry:     # stand-in for the kernel: row i = f(global trace index, batch)
+            idx = torch.arange(rank * n, (rank + 1) * n, dtype=torch.float32)
+            dst.copy_(idx[:, None] + 1000.0 * k if workload == "icpc" else idx[None, :].expand(2, n))
+        elif workload == "icpc":
+            ldsp.icpc_run(wf, params, ctx, out=dst)
+        else:
+            ldsp.icpc_pz_trap_run(wf, params, ctx, out=dst)
 
     # N > 1: the table of batch k travels to rank 0 (RCCL, its own stream) while the kernel of batch k+1 runs: two output
     # tables per rank, two gathered tables on rank 0, and a table is overwritten only after its gather has completed
-    pipe = world > 1 and args.workload == "icpc"
+    pipe = world > 1 and workload == "icpc"
     outs = [out, torch.empty_like(out)] if pipe else [out]
     gathered = [torch.empty((n * world, ncol), dtype=torch.float32, device=dev) for _ in range(2)] if (pipe and rank == 0) else [None, None]
     works = [None, None]
     count = [0]
 
     def step():
-        if args.workload == "icpc":
-            k = count[0] % len(outs)
-            count[0] += 1
-            if works[k] is not None:
-                works[k].wait()                      # the gather that read outs[k] two batches ago
-                works[k] = None
-            ldsp.icpc_run(wf, params, ctx, out=outs[k])
-            if pipe:
-                _, works[k] = ldist.gather_table(outs[k], n * world, dst=0, out=gathered[k], async_op=True)
-        else:
-            ldsp.icpc_pz_trap_run(wf, params, ctx, out=out)
+        k = count[0] % len(outs)
+        if works[k] is not None:
+            works[k].wait()                      # the gather that read outs[k] two batches ago
+            works[k] = None
+        kernel(outs[k], count[0])
+        count[0] += 1
+        if pipe:
+            _, works[k] = ldist.gather_table(outs[k], n * world, dst=0, out=gathered[k], async_op=True)
 
-    def fence():
+    def finish():
         for k in range(2):
             if works[k] is not None:
-                works[k].wait()                      # every gather issued so far is inside the timed region
+                works[k].wait()                  # every gather issued so far is inside the timed region
                 works[k] = None
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    kernel_ms, stage_ms = [], [[], []]
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        if rank == 0 and world == 1:
-            pass
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(env, args, step, finish)
+    res = None
+    if env.dry:
+        if rank == 0:
+            ok = True
+            if pipe:    # the last two batches arrived intact, rank blocks in place
+                for k in range(2):
+                    b = count[0] - 1 - ((count[0] - 1 - k) % 2)
+                    exp = torch.arange(n * world, dtype=torch.float32)[:, None] + 1000.0 * b
+                    ok = ok and bool((gathered[k] == exp).all())
+            res = {"metric": "dry run (launcher + gather rehearsal on CPU, no kernel)", "value": None, "unit": "waveforms/s",
+                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "gather_ok": ok,
+                   "config": {"workload": workload, "traces_per_gpu": n, "samples": L}}
+            if not ok:
+                raise SystemExit("dry run: gathered table differs from the expected rows")
+        return res, None
+
     # per-launch duration of the dominant kernel, HIP events on the launch stream
+    kernel_ms, stage_ms = [], [[], []]
     for _ in range(3):
-        if args.workload == "icpc":
-            ldsp.icpc_run(wf, params, ctx, out=out)
-        else:
-            ldsp.icpc_pz_trap_run(wf, params, ctx, out=out)
+        kernel(out, 0)
         kernel_ms.append(ctx.last_kernel_ms())
-        if args.workload == "icpc":
+        if workload == "icpc":
             stage_ms[0].append(ctx.last_stage_ms(0))
             try:   # two launches only when the CUSP/ZAC stage could not be fused (see DESIGN.md section 3)
                 stage_ms[1].append(ctx.last_stage_ms(1))
             except ldsp.LdspError:
                 pass
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    env.sync()
     if rank == 0:
-        total = n * world * args.steps
-        wps = total / elapsed
+        wps = n * world * args.steps / elapsed
         kms = sum(kernel_ms) / len(kernel_ms)
         # SURVEY §8(d): one trace read (4L) + one output row written (4 bytes x 48 columns).  dsp_icpc runs as ONE
         # launch of icpc_kernel (CUSP/ZAC fused in, DESIGN.md section 3), so the dominant kernel's algorithmic bytes are
         # the path's.  If the fused form was not applicable (two launches), icpc_kernel writes 42 columns + a
         # 16-byte hand-over record and icpc_cz_kernel reads the trace again and writes the other 6.
-        chain_bytes = 4 * L + (4 * ncol if args.workload == "icpc" else 8)
-        fused = args.workload == "icpc" and not stage_ms[1]
-        if args.workload == "icpc":
+        chain_bytes = 4 * L + (4 * ncol if workload == "icpc" else 8)
+        fused = workload == "icpc" and not stage_ms[1]
+        if workload == "icpc":
             k1 = sum(stage_ms[0]) / len(stage_ms[0])
             k2 = sum(stage_ms[1]) / len(stage_ms[1]) if stage_ms[1] else 0.0
             bytes_per_trace = chain_bytes if fused else 4 * L + 4 * 42 + 16
@@ -228,10 +275,9 @@ def main():
         else:
             bytes_per_trace, dom_ms = chain_bytes, kms
         achieved = n * bytes_per_trace / (dom_ms * 1e-3) / 1e9
-        dom_kernel = "icpc_kernel" if args.workload == "icpc" else "pz_trap_kernel"
-        traffic = measured_traffic(dom_kernel, n, L)
+        dom_kernel = "icpc_kernel" if workload == "icpc" else "pz_trap_kernel"
         res = {
-            "metric": "waveforms/s, full dsp_icpc chain, 8192-sample f32" if args.workload == "icpc"
+            "metric": "waveforms/s, full dsp_icpc chain, 8192-sample f32" if workload == "icpc"
             else "waveforms/s, pole-zero + trapezoid sub-chain, 8192-sample f32",
             "value": wps, "unit": "waveforms/s",
             "msamples_per_s": wps * L / 1e6,
@@ -239,50 +285,178 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"BASELINE config 3: {n} x {L} f32, full dsp_icpc chain" if args.workload == "icpc"
-                                    else f"BASELINE config 2: {n} x {L} f32, pole-zero + trapezoid"),
+            "config": {"workload": (f"BASELINE config {3 if world == 1 else 4}: {n}{' per GPU' if world > 1 else ''} x {L} f32, full dsp_icpc chain"
+                                    if workload == "icpc" else f"BASELINE config 2: {n} x {L} f32, pole-zero + trapezoid"),
                        "traces_per_gpu": n, "samples": L, "dt_ns": dt,
                        "dsp_config": "reference test/test_dsp_icpc.jl:50-161", "tau_us": 500,
-                       "gather": "rccl gather of [n,48] f32 to rank 0, overlapped with the next batch's kernel (double-buffered)" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": dom_kernel,
-                         "kernel_ms": dom_ms, "algorithmic_bytes_per_trace": bytes_per_trace},
+                       "gather": "rccl gather of [n,48] f32 to rank 0, overlapped with the next batch's kernel (double-buffered)" if pipe else "none"},
+            "roofline": roofline(achieved, dom_kernel, dom_ms, bytes_per_trace, measured_traffic(dom_kernel, n, L)),
         }
-        if traffic:
-            res["roofline"]["traffic"] = traffic["bytes"]
-            res["roofline"]["traffic_source"] = traffic["source"]
-        if args.workload == "icpc":
+        if workload == "icpc":
             res["roofline"]["launches"] = "1 (icpc_kernel, CUSP/ZAC fused)" if fused else "2 (icpc_kernel + icpc_cz_kernel)"
             if not fused:
                 res["roofline"]["chain"] = {  # both kernels together against the path's algorithmic bytes
                     "kernels_ms": {"icpc_kernel": k1, "icpc_cz_kernel": k2}, "algorithmic_bytes_per_trace": chain_bytes,
                     "achieved": n * chain_bytes / (kms * 1e-3) / 1e9, "frac": n * chain_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if world == 1 and args.cpu_sample > 0 and args.workload == "icpc":
-            from oracle import oracle as orc  # checker / CPU baseline only
-            orc.build()
-            m = min(args.cpu_sample, n)
-            host = wf[:m].cpu().numpy()
-            cores = min(os.cpu_count() or 1, 16)
-            orc.dsp_icpc(host[:cores], params, nthreads=cores)  # warm-up (thread pool, LSQ bases)
-            t1 = time.perf_counter()
-            orc.dsp_icpc(host, params, nthreads=cores)
-            cpu_t = time.perf_counter() - t1
-            # the reference itself is single-threaded: the same restatement on one core, smaller sample
-            m1 = min(2048, m)
-            t2 = time.perf_counter()
-            orc.dsp_icpc(host[:m1], params, nthreads=1)
-            cpu_t1 = time.perf_counter() - t2
-            res["cpu_baseline"] = {
-                "value": m / cpu_t, "unit": "waveforms/s", "cores": cores, "kind": "port",
-                "single_thread": {"value": m1 / cpu_t1, "unit": "waveforms/s", "cores": 1, "sample": f"first {m1} traces"},
-                "sample": f"first {m} traces of the same batch, float64 CPU restatement (oracle/ldsp_oracle.c), "
-                          f"OpenMP over traces, direct-form CUSP/ZAC; proxy for the single-threaded Julia reference",
-            }
-        print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+        if world == 1 and args.cpu_sample > 0 and workload == "icpc":
+            res["cpu_baseline"] = cpu_baseline(args, wf, params, n)
+    return res, wf
+
+
+def cpu_baseline(args, wf, params, n):
+    from oracle import oracle as orc  # checker / CPU baseline only
+    orc.build()
+    m = min(args.cpu_sample, n)
+    host = wf[:m].cpu().numpy()
+    cores = min(os.cpu_count() or 1, 16)
+    orc.dsp_icpc(host[:cores], params, nthreads=cores)  # warm-up (thread pool, LSQ bases)
+    t1 = time.perf_counter()
+    orc.dsp_icpc(host, params, nthreads=cores)
+    cpu_t = time.perf_counter() - t1
+    # the reference itself is single-threaded: the same restatement on one core, smaller sample
+    m1 = min(2048, m)
+    t2 = time.perf_counter()
+    orc.dsp_icpc(host[:m1], params, nthreads=1)
+    cpu_t1 = time.perf_counter() - t2
+    return {
+        "value": m / cpu_t, "unit": "waveforms/s", "cores": cores, "kind": "port",
+        "single_thread": {"value": m1 / cpu_t1, "unit": "waveforms/s", "cores": 1, "sample": f"first {m1} traces"},
+        "sample": f"first {m} traces of the same batch, float64 CPU restatement (oracle/ldsp_oracle.c), "
+                  f"OpenMP over traces, direct-form CUSP/ZAC; proxy for the single-threaded Julia reference",
+    }
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# dsp_sipm (config 5)
+
+SIPM_GROUPS = ("trig", "trig_DC", "trig_trap", "trig_DC_trap")
+SIPM_FIELDS = ("x", "x_high", "x_tot", "max")
+
+
+def bench_sipm(env, args, n, L):
+    """dsp_sipm (reference src/dsp_sipm.jl:47-158): weak scaling, each rank its own shard.  N > 1: the 20 scalar columns
+    travel as one table, every trigger group's ragged columns (reference :149-156) as counts + compacted payload
+    (`dist.gather_ragged`), all inside the timed region."""
+    torch = env.torch
+    from legenddsp_jl_amd import dist as ldist
+    world, rank, dev = env.world, env.rank, env.dev
+    if not env.dry:
+        import legenddsp_jl_amd as ldsp
+        from legenddsp_jl_amd.extractors import compact_fields
+        from legenddsp_jl_amd.routines import sipm_resolve_overflow
+        params = ldsp.lower_sipm(ldsp.reference_test_sipm_config(), {"sg": {"wl": 200 * ldsp.ns}}, L, 0.0, 16.0)
+        wf = torch.empty((n, L), dtype=torch.float32, device=dev)
+        ldsp.synth.sipm_batch(n, L, device=dev, out=wf, first_trace=rank * n)
+        ctx = ldsp.Context(dev.index)
+        ctx.enable_timing(True)
+        bufs = ldsp.sipm_run(wf, params, ctx)      # allocates the output buffers once
+    gathered = {}
+
+    def step():
+        if env.dry:   # stand-in: trace i of the job has (i % 5) + g triggers in group g, element value = global trace index
+            idx = torch.arange(rank * n, (rank + 1) * n)
+            sc = idx[:, None].to(torch.float32).expand(n, 20).contiguous()
+            rag = {}
+            for g, name in enumerate(SIPM_GROUPS):
+                cnt = (idx % 5) + g
+                rag[name] = (torch.repeat_interleave(idx, cnt).to(torch.float32)[:, None].expand(-1, 4).contiguous(), cnt)
+        else:
+            sc_t, trig = ldsp.sipm_run(wf, params, ctx, out=bufs)
+            if world == 1:
+                return
+            sc = sc_t.t().contiguous()
+            trig = sipm_resolve_overflow(wf, params, ctx, trig)     # traces with more triggers than a slab holds run again
+            rag = {g: compact_fields(trig[g], SIPM_FIELDS) for g in SIPM_GROUPS}
+        if world > 1:
+            gathered["scalars"] = ldist.gather_table(sc, n * world, dst=0)
+            for g in SIPM_GROUPS:
+                gathered[g] = ldist.gather_ragged(rag[g][0], rag[g][1], n * world, dst=0)
+
+    elapsed = timed(env, args, step)
+    if env.dry:
+        res = None
+        if rank == 0:
+            ok = True
+            if world > 1:
+                idx = torch.arange(n * world)
+                ok = bool((gathered["scalars"][:, 0] == idx.to(torch.float32)).all())
+                for g, name in enumerate(SIPM_GROUPS):
+                    off, val = gathered[name]
+                    cnt = (idx % 5) + g
+                    ok = ok and bool((off[1:] - off[:-1] == cnt).all()) and bool((val[:, 0] == torch.repeat_interleave(idx, cnt).to(torch.float32)).all())
+            res = {"metric": "dry run (launcher + scalar and ragged gather rehearsal on CPU, no kernel)", "value": None, "unit": "waveforms/s",
+                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "gather_ok": ok,
+                   "config": {"workload": "sipm", "traces_per_gpu": n, "samples": L}}
+            if not ok:
+                raise SystemExit("dry run: gathered sipm columns differ from the expected rows")
+        return res
+    kms = []
+    for _ in range(3):
+        ldsp.sipm_run(wf, params, ctx, out=bufs)
+        kms.append(ctx.last_kernel_ms())
+    env.sync()
+    res = None
+    if rank == 0:
+        kms = sum(kms) / len(kms)
+        # the 12 ragged columns the table keeps (reference :149-156): x, max of the two SG groups, all four fields of the trapezoid groups
+        per_group = {"trig": 2, "trig_DC": 2, "trig_trap": 4, "trig_DC_trap": 4}
+        elems = sum(int(bufs[1][g]["count"].sum()) * per_group[g] for g in bufs[1])
+        bytes_per_trace = 4 * L + 4 * 20 + 8.0 * elems / n      # SURVEY 8(d), C5: measured ragged element count
+        achieved = n * bytes_per_trace / (kms * 1e-3) / 1e9
+        wps = n * world * args.steps / elapsed
+        res = {
+            "metric": "waveforms/s, fused dsp_sipm, 16384-sample f32", "value": wps, "unit": "waveforms/s",
+            "msamples_per_s": wps * L / 1e6, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (the reference forces Float64, src/dsp_sipm.jl:87-88)", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 5 shape: dsp_sipm, {n}{' per GPU' if world > 1 else ''} x {L} f32 traces", "traces_per_gpu": n, "samples": L,
+                       "dt_ns": 16.0, "dsp_config": "reference test/test_dsp_sipm.jl:38-68 + sg.wl = 200 ns",
+                       "ragged_elements_per_trace": elems / n,
+                       "gather": "rccl: scalar table + per trigger group counts -> scan on root -> payload (per-peer sizes)" if world > 1 else "none"},
+            "roofline": roofline(achieved, "k_sipm_s4", kms, bytes_per_trace, measured_traffic("k_sipm_s4", n, L)),
+        }
+    del wf, bufs
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------
+
+def run_rank(args):
+    sys.path.insert(0, ROOT)
+    env = Env(args)
+    multi = env.world > 1
+    try:
+        if args.workload == "sipm":
+            n = args.n if args.n is not None else 625_000
+            L = args.L if args.L is not None else 16384
+            res = bench_sipm(env, args, n, L)
+        else:
+            n = args.n if args.n is not None else (1_250_000 if (multi and args.workload == "icpc") else 1_000_000)
+            L = args.L if args.L is not None else 8192
+            res, wf = bench_icpc(env, args, n, L, args.workload)
+            if (not multi and not env.dry and args.workload == "icpc" and not args.no_secondary and env.rank == 0
+                    and args.n is None and args.L is None):
+                sec = []
+                r2, _ = bench_icpc(env, args, n, L, "pz_trap", wf=wf)      # BASELINE config 2 on the same batch
+                sec.append(r2)
+                del wf
+                env.torch.cuda.empty_cache()
+                sec.append(bench_sipm(env, args, 625_000, 16384))         # BASELINE config 5's single-GPU shard
+                res["secondary"] = sec
+        if env.rank == 0:
+            print(json.dumps(res), flush=True)
+    finally:
+        env.close()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

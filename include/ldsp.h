@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LDSP_ABI_VERSION 1
+#define LDSP_ABI_VERSION 2
 
 typedef enum {
   LDSP_OK = 0,
@@ -93,7 +93,7 @@ int ldsp_ctx_last_stage_ms(ldsp_ctx* ctx, int stage, float* ms);
 #define LDSP_MAX_EST_DEG 5
 #define LDSP_MAX_SG_PTS 65      /* Savitzky-Golay taps                         */
 #define LDSP_MAX_FIR_TAPS 8192  /* generic valid-mode FIR (CUSP/ZAC/SG)        */
-#define LDSP_MAX_TRIG 64        /* IntersectMaximum: triggers kept per trace   */
+#define LDSP_MAX_TRIG 64        /* IntersectMaximum: default slab capacity (ldsp_trig_out.cap = 0) */
 #define LDSP_MAX_MULTI 128      /* MultiIntersect: thresholds per trace        */
 
 /* ---- lowered parameter blocks ------------------------------------------ */
@@ -217,12 +217,16 @@ typedef struct {
   double trap_min_dc_thr, trap_max_dc_thr, trap_nsigma_dc; /* :137-138 */
 } ldsp_sipm_params;
 
-/* Ragged column = fixed-capacity slab [n][LDSP_MAX_TRIG] + count[n]; the host
- * wrapper compacts to (offsets, values) = VectorOfVectors.  count holds the
- * true multiplicity even if it exceeds the capacity (overflow is detectable). */
+/* Ragged column = slab [n][cap] + count[n]; the host wrapper compacts to (offsets, values) =
+ * VectorOfVectors.  The reference returns EVERY up-crossing (src/intersect_maximum.jl:49-56): count
+ * holds the true multiplicity even when it exceeds `cap`, and a caller that finds count > cap runs the
+ * affected traces again with slabs of that capacity (two-pass count-then-fill; the Python host does so,
+ * `extractors.resolve_overflow`) — nothing is dropped silently.  cap = 0 means LDSP_MAX_TRIG. */
 typedef struct {
   int32_t* count; /* [n]                    */
-  float *x, *x_high, *x_tot, *max; /* each [n][LDSP_MAX_TRIG], may be NULL */
+  float *x, *x_high, *x_tot, *max; /* each [n][cap], may be NULL */
+  int32_t cap;    /* slab capacity per trace (row stride); 0 = LDSP_MAX_TRIG */
+  int32_t _pad;
 } ldsp_trig_out;
 
 typedef struct {

@@ -4,7 +4,7 @@ Pure declarations: importing this module loads no native code.
 """
 import ctypes as C
 
-LDSP_ABI_VERSION = 1
+LDSP_ABI_VERSION = 2
 LDSP_OK = 0
 LDSP_ERR_INVALID_ARG = -1
 LDSP_ERR_WINDOW = -2
@@ -110,7 +110,7 @@ class SipmParams(C.Structure):
 
 class TrigOut(C.Structure):
     _fields_ = [("count", C.c_void_p), ("x", C.c_void_p), ("x_high", C.c_void_p),
-                ("x_tot", C.c_void_p), ("max", C.c_void_p)]
+                ("x_tot", C.c_void_p), ("max", C.c_void_p), ("cap", C.c_int32), ("_pad", C.c_int32)]
 
 
 SIPM_SCALAR_COLS = [

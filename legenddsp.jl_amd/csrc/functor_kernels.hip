@@ -358,8 +358,8 @@ __global__ void __launch_bounds__(256) k_intersect_maximum(const float* __restri
   const float th = thr[blockIdx.x];
   tb::build_mask(l.s, L, 1.f, th, l.bm);
   __syncthreads();
-  const size_t off = (size_t)blockIdx.x * LDSP_MAX_TRIG;
-  const int total = intersect_maximum_block(l.s, L, 1.f, th, min_n, max_n, t_first, dt, l.bm, *l.sc, LDSP_MAX_TRIG,
+  const size_t off = (size_t)blockIdx.x * (size_t)o.cap;
+  const int total = intersect_maximum_block(l.s, L, 1.f, th, min_n, max_n, t_first, dt, l.bm, *l.sc, o.cap,
                                             o.x ? o.x + off : nullptr, o.x_high ? o.x_high + off : nullptr,
                                             o.x_tot ? o.x_tot + off : nullptr, o.max ? o.max + off : nullptr, nullptr);
   if (threadIdx.x == 0 && o.count) o.count[blockIdx.x] = total;
@@ -672,9 +672,11 @@ int ldsp_intersect(ldsp_ctx* c, const float* x, int64_t n, int32_t L, double t_f
 int ldsp_intersect_maximum(ldsp_ctx* c, const float* x, int64_t n, int32_t L, double t_first, double dt, const float* thr,
                            int32_t min_n, int32_t max_n, const ldsp_trig_out* out) {
   STATS_COMMON("ldsp_intersect_maximum");
-  if (!thr || !out || min_n < 1 || max_n < 1) return ldsp_fail(LDSP_ERR_INVALID_ARG, "bad IntersectMaximum arguments");
+  if (!thr || !out || min_n < 1 || max_n < 1 || out->cap < 0) return ldsp_fail(LDSP_ERR_INVALID_ARG, "bad IntersectMaximum arguments");
   if ((rc = set_lds(k_intersect_maximum, b))) return rc;
-  hipLaunchKernelGGL(k_intersect_maximum, dim3((unsigned)n), dim3(256), b, c->stream, x, L, (float)t_first, (float)dt, thr, min_n, max_n, *out);
+  ldsp_trig_out o = *out;
+  if (o.cap == 0) o.cap = LDSP_MAX_TRIG;
+  hipLaunchKernelGGL(k_intersect_maximum, dim3((unsigned)n), dim3(256), b, c->stream, x, L, (float)t_first, (float)dt, thr, min_n, max_n, o);
   LAUNCH_CHECK();
   return LDSP_OK;
 }

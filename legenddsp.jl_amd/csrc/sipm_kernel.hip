@@ -97,8 +97,8 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
     if (tid == 0) sc.f[1] = 0.f;  // minimum.(inters.x; init = 0)
     __syncthreads();
     const ldsp_trig_out& o = out.trig[0];
-    const size_t off = b * LDSP_MAX_TRIG;
-    const int tot = intersect_maximum_block(B, ng, 1.f, th, P.sg_mintot, P.sg_maxtot, tg, P.dt, bm, sc, LDSP_MAX_TRIG,
+    const size_t off = b * (size_t)o.cap;
+    const int tot = intersect_maximum_block(B, ng, 1.f, th, P.sg_mintot, P.sg_maxtot, tg, P.dt, bm, sc, o.cap,
                                             o.x ? o.x + off : nullptr, o.x_high ? o.x_high + off : nullptr,
                                             o.x_tot ? o.x_tot + off : nullptr, o.max ? o.max + off : nullptr, &sc.f[1]);
     if (tid == 0 && o.count) o.count[b] = tot;
@@ -131,8 +131,8 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
     tb::build_mask(B, ng, -1.f, th, bm);
     __syncthreads();
     const ldsp_trig_out& o = out.trig[v ? 3 : 1];
-    const size_t off = b * LDSP_MAX_TRIG;
-    const int tot = intersect_maximum_block(B, ng, -1.f, th, P.sg_mintot, P.sg_maxtot, tg, P.dt, bm, sc, LDSP_MAX_TRIG,
+    const size_t off = b * (size_t)o.cap;
+    const int tot = intersect_maximum_block(B, ng, -1.f, th, P.sg_mintot, P.sg_maxtot, tg, P.dt, bm, sc, o.cap,
                                             o.x ? o.x + off : nullptr, o.x_high ? o.x_high + off : nullptr,
                                             o.x_tot ? o.x_tot + off : nullptr, o.max ? o.max + off : nullptr, nullptr);
     if (tid == 0 && o.count) o.count[b] = tot;
@@ -183,8 +183,8 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
     tb::build_mask(B, nt, 1.f, th, bm);
     __syncthreads();
     const ldsp_trig_out& o = out.trig[2];
-    const size_t off = b * LDSP_MAX_TRIG;
-    const int tot = intersect_maximum_block(B, nt, 1.f, th, P.trap_mintot, P.trap_maxtot, tt, P.dt, bm, sc, LDSP_MAX_TRIG,
+    const size_t off = b * (size_t)o.cap;
+    const int tot = intersect_maximum_block(B, nt, 1.f, th, P.trap_mintot, P.trap_maxtot, tt, P.dt, bm, sc, o.cap,
                                             o.x ? o.x + off : nullptr, o.x_high ? o.x_high + off : nullptr,
                                             o.x_tot ? o.x_tot + off : nullptr, o.max ? o.max + off : nullptr, nullptr);
     if (tid == 0 && o.count) o.count[b] = tot;
@@ -240,6 +240,10 @@ extern "C" int ldsp_sipm_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp
   static_assert(sizeof(ldsp_sipm_out) == sizeof(void*) * sipm::S_NCOLS + 4 * sizeof(ldsp_trig_out), "ldsp_sipm_out layout");
   memcpy(od.col, out, sizeof(void*) * sipm::S_NCOLS);
   od.trig[0] = out->trig; od.trig[1] = out->trig_DC; od.trig[2] = out->trig_trap; od.trig[3] = out->trig_DC_trap;
+  for (auto& t : od.trig) {
+    if (t.cap < 0) return ldsp_fail(LDSP_ERR_INVALID_ARG, "ldsp_trig_out.cap must be >= 0");
+    if (t.cap == 0) t.cap = LDSP_MAX_TRIG;
+  }
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   // register-resident kernel (one LDS copy of the trace, two traces per CU) when the trace fills a tile and the
   // filters are the usual short ones; otherwise the generic two-array kernel

@@ -61,3 +61,50 @@ def gather_table(tab: torch.Tensor, n_total: int, dst: int = 0, group=None, out:
         lo, hi = shard_range(n_total, world, r)
         parts.append(bufs[r][: hi - lo])
     return torch.cat(parts, dim=0)
+
+
+def gather_ragged(values: torch.Tensor, counts: torch.Tensor, n_total: int, dst: int = 0, group=None):
+    """Gather one ragged column family (counts -> exclusive scan on root -> payload).
+
+    `counts` [n_r]: elements per trace of this rank's shard (trace order); `values` [sum(counts), F]: the shard's
+    compacted elements, F fields per element (e.g. x, x_high, x_tot, max of one IntersectMaximum call — the
+    `VectorOfVectors` columns of reference src/dsp_sipm.jl:149-156 share their offsets per trigger group).
+    Returns `(offsets [n_total + 1] int64, values [sum over ranks, F])` on `dst` — `values[offsets[i]:offsets[i+1]]`
+    is global trace i — and None elsewhere.
+
+    Three steps: (1) the per-trace counts travel as a one-column table (`gather_table`, fixed size); (2) the root
+    scans them: offsets of every trace, and from the shard ranges the element total and start of every peer;
+    (3) the payloads, whose sizes differ per peer, travel as point-to-point transfers straight into their place in
+    the result (RCCL: one ncclGroup of send/recv over the direct xGMI links; gloo in the CPU tests).  Peers with no
+    elements send nothing."""
+    if values.dim() == 1:
+        values = values[:, None]
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        off = torch.zeros(len(counts) + 1, dtype=torch.int64, device=counts.device)
+        off[1:] = torch.cumsum(counts.to(torch.int64), 0)
+        return off, values
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if int(values.shape[0]) != int(counts.sum()):
+        raise ValueError("values must hold exactly sum(counts) rows")
+    cnt = gather_table(counts.to(torch.int64)[:, None].contiguous(), n_total, dst=dst, group=group)
+    if rank != dst:
+        if values.shape[0] > 0:
+            dist.batch_isend_irecv([dist.P2POp(dist.isend, values.contiguous(), dst, group)])[-1].wait()
+        return None
+    cnt = cnt[:, 0]
+    offsets = torch.zeros(n_total + 1, dtype=torch.int64, device=cnt.device)
+    offsets[1:] = torch.cumsum(cnt, 0)
+    bounds = [shard_range(n_total, world, r) for r in range(world)]
+    starts = offsets[torch.tensor([b[0] for b in bounds] + [n_total], device=offsets.device)].tolist()   # one host read
+    out = torch.empty((starts[-1], values.shape[1]), dtype=values.dtype, device=values.device)
+    ops = []
+    for r in range(world):
+        lo, hi = starts[r], starts[r + 1]
+        if r == rank:
+            out[lo:hi] = values
+        elif hi > lo:
+            ops.append(dist.P2POp(dist.irecv, out[lo:hi], r, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return offsets, out

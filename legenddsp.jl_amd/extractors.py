@@ -68,13 +68,73 @@ class VectorOfVectors:
         return self.values[int(self.offsets[i]):int(self.offsets[i + 1])]
 
 
-def _compact(slab: torch.Tensor, count: torch.Tensor) -> VectorOfVectors:
-    cap = slab.shape[1]
-    kept = count.clamp(max=cap).to(torch.int64)
-    offsets = torch.zeros(len(count) + 1, dtype=torch.int64, device=slab.device)
-    offsets[1:] = torch.cumsum(kept, 0)
-    mask = torch.arange(cap, device=slab.device)[None, :] < kept[:, None]
-    return VectorOfVectors(offsets, slab[mask])
+class TriggerOverflow(_lib.LdspError):
+    """A trace produced more triggers than its slab holds and the caller gave no way to run it again."""
+
+
+def compact_fields(t: dict, fields=("x", "x_high", "x_tot", "max")):
+    """Compact the slabs of one trigger group (`count` [n], one [n, cap] slab per field, optionally an `overflow`
+    record = the same for the traces whose count exceeded cap, re-run with larger slabs by `resolve_overflow`) into
+    `(values [sum(count), len(fields)], count [n] int64)`: EVERY trigger of every trace, in trace order — what the
+    reference's `VectorOfVectors` columns hold (src/intersect_maximum.jl:49-56 pushes every crossing).  Work is
+    proportional to the number of triggers, not to n x cap.  Raises TriggerOverflow if a count exceeds its slab and no
+    overflow record covers it."""
+    count = t["count"].to(torch.int64)
+    n, dev = len(count), count.device
+    cap = t[fields[0]].shape[1]
+    ovf = t.get("overflow")
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    offsets[1:] = torch.cumsum(count, 0)
+    total = int(offsets[-1])
+    row = torch.repeat_interleave(torch.arange(n, device=dev), count, output_size=total)
+    pos = torch.arange(total, device=dev) - offsets[row]
+    over = pos >= cap
+    if ovf is None:
+        if total and bool(over.any()):
+            raise TriggerOverflow(-104, f"a trace has more than {cap} triggers: call resolve_overflow() first")
+        vals = torch.stack([t[f][row, pos] for f in fields], dim=1) if total else torch.empty((0, len(fields)), dtype=torch.float32, device=dev)
+        return vals, count
+    slot = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    slot[ovf["rows"]] = torch.arange(len(ovf["rows"]), device=dev)
+    use2 = slot[row] >= 0                      # every element of a re-run trace comes from the larger slabs
+    if bool((over & ~use2).any()) or bool((ovf["count"].to(torch.int64) != count[ovf["rows"]]).any()):
+        raise TriggerOverflow(-104, "overflow record does not cover every overflowing trace")
+    cols = []
+    for f in fields:
+        a = t[f][row, pos.clamp(max=cap - 1)]
+        b = ovf[f][slot[row].clamp(min=0), pos.clamp(max=ovf[f].shape[1] - 1)]
+        cols.append(torch.where(use2, b, a))
+    return torch.stack(cols, dim=1), count
+
+
+def _compact_group(t: dict, fields):
+    """-> ({field: VectorOfVectors}, count) of one trigger group (shared offsets)."""
+    vals, count = compact_fields(t, fields)
+    offsets = torch.zeros(len(count) + 1, dtype=torch.int64, device=count.device)
+    offsets[1:] = torch.cumsum(count, 0)
+    return {f: VectorOfVectors(offsets, vals[:, i].contiguous()) for i, f in enumerate(fields)}, count
+
+
+def resolve_overflow(groups: dict, rerun):
+    """Two-pass count-then-fill.  `groups`: {name: trigger-group dict}.  If any trace of any group counted more triggers
+    than its slab holds, `rerun(rows, cap)` must run exactly those traces again with slabs of capacity `cap` and return
+    the same structure; its result is attached as the `overflow` record `compact_fields` reads.  One host read."""
+    names = list(groups)
+    cap = {g: groups[g]["x"].shape[1] for g in names}
+    mx = torch.stack([groups[g]["count"].max() if len(groups[g]["count"]) else torch.zeros((), dtype=torch.int32, device=groups[g]["count"].device)
+                      for g in names]).tolist()
+    if all(m <= cap[g] for m, g in zip(mx, names)):
+        return groups
+    over = None
+    for g in names:
+        o = groups[g]["count"] > cap[g]
+        over = o if over is None else (over | o)
+    rows = torch.nonzero(over)[:, 0]
+    cap2 = 1 << (int(max(mx)) - 1).bit_length()
+    again = rerun(rows, cap2)
+    for g in names:
+        groups[g]["overflow"] = dict(rows=rows, **{k: v for k, v in again[g].items() if k != "overflow"})
+    return groups
 
 
 def signalstats(w: ArrayOfRDWaveforms, start, stop):
@@ -174,13 +234,21 @@ class IntersectMaximum:
             return dict(x=empty(), x_high=empty(), x_tot=empty(), max=empty(), multiplicity=torch.zeros(n, dtype=torch.int32, device=dev))
         thr = _per_trace(threshold, n, dev)
         min_n, max_n = max(1, nsamples(self.mintot, w.dt)), max(1, nsamples(self.maxtot, w.dt))
-        cap = _abi.LDSP_MAX_TRIG
-        count = _i(n, dev)
-        slabs = {k: torch.full((n, cap), float("nan"), dtype=torch.float32, device=dev) for k in ("x", "x_high", "x_tot", "max")}
-        o = _abi.TrigOut(count.data_ptr(), *[slabs[k].data_ptr() for k in ("x", "x_high", "x_tot", "max")])
-        _lib.check(_lib.lib().ldsp_intersect_maximum(ctx.handle, _vp(x), n, x.shape[1], w.t_first, w.dt, _vp(thr), min_n, max_n, C.byref(o)))
-        res = {k: _compact(v, count) for k, v in slabs.items()}
-        res["multiplicity"] = count
+        fields = ("x", "x_high", "x_tot", "max")
+
+        def run(xs, ths, cap):
+            m = xs.shape[0]
+            count = _i(m, dev)
+            slabs = {k: torch.full((m, cap), float("nan"), dtype=torch.float32, device=dev) for k in fields}
+            o = _abi.TrigOut(count.data_ptr(), *[slabs[k].data_ptr() for k in fields], cap, 0)
+            _lib.check(_lib.lib().ldsp_intersect_maximum(ctx.handle, _vp(xs), m, xs.shape[1], w.t_first, w.dt, _vp(ths), min_n, max_n, C.byref(o)))
+            return dict(count=count, **slabs)
+
+        # every crossing is returned (src/intersect_maximum.jl:49-56): traces with more triggers than the default slab run again
+        grp = resolve_overflow({"t": run(x, thr, _abi.LDSP_MAX_TRIG)},
+                               lambda rows, cap: {"t": run(x.index_select(0, rows).contiguous(), thr.index_select(0, rows).contiguous(), cap)})["t"]
+        res, count = _compact_group(grp, fields)
+        res["multiplicity"] = grp["count"]
         return res
 
 

@@ -146,9 +146,11 @@ def dsp_icpc(data: Table, config: DSPConfig, tau: float, pars_filter: dict, f_ev
 # ---------------------------------------------------------------------------
 # dsp_sipm
 
-def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None, out=None):
+def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None, out=None, cap: int = None):
     """Run the fused dsp_sipm kernel (`ldsp_sipm_run`).  Returns (scalars [20, n] float32,
-    {group: {count [n] int32, x/x_high/x_tot/max [n, LDSP_MAX_TRIG] float32}}).
+    {group: {count [n] int32, x/x_high/x_tot/max [n, cap] float32}}), cap = LDSP_MAX_TRIG by default.
+    `count` is the TRUE multiplicity: where it exceeds cap the slab holds the first cap triggers only and
+    `sipm_resolve_overflow` (called by `dsp_sipm`) runs those traces again with larger slabs.
     `out`: the pair returned by an earlier call on a batch of the same size — its buffers are reused
     without re-initialisation (slab entries beyond `count` then keep their old contents)."""
     if not wf.is_cuda:
@@ -159,11 +161,19 @@ def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None
         raise ValueError(f"waveform length {L} != params.L {params.L}")
     wf = _as_device_f32(wf, wf.device)
     dev = wf.device
-    cap = _abi.LDSP_MAX_TRIG
+    cap = int(cap) if cap else _abi.LDSP_MAX_TRIG
     if out is not None:
         sc, trig = out
-        if sc.shape != (len(_abi.SIPM_SCALAR_COLS), n) or sc.device != dev:
+        if sc.shape != (len(_abi.SIPM_SCALAR_COLS), n) or sc.device != dev or sc.dtype != torch.float32 or not sc.is_contiguous():
             raise ValueError("out= buffers do not match this batch")
+        for g in _abi.SIPM_TRIG_GROUPS:
+            t = trig[g]
+            t.pop("overflow", None)
+            if t["count"].shape != (n,) or t["count"].dtype != torch.int32 or t["count"].device != dev:
+                raise ValueError(f"out=: count buffer of group {g} does not match this batch")
+            for k in ("x", "x_high", "x_tot", "max"):
+                if t[k].shape != (n, t["x"].shape[1]) or t[k].dtype != torch.float32 or t[k].device != dev or not t[k].is_contiguous():
+                    raise ValueError(f"out=: slab {g}.{k} does not match this batch")
     else:
         sc = torch.full((len(_abi.SIPM_SCALAR_COLS), n), float("nan"), dtype=torch.float32, device=dev)
         trig = {}
@@ -176,20 +186,30 @@ def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None
         setattr(o, c, sc[i].data_ptr())
     for g in _abi.SIPM_TRIG_GROUPS:
         t = trig[g]
-        setattr(o, g, _abi.TrigOut(t["count"].data_ptr(), t["x"].data_ptr(), t["x_high"].data_ptr(), t["x_tot"].data_ptr(), t["max"].data_ptr()))
+        setattr(o, g, _abi.TrigOut(t["count"].data_ptr(), t["x"].data_ptr(), t["x_high"].data_ptr(), t["x_tot"].data_ptr(), t["max"].data_ptr(),
+                                   t["x"].shape[1], 0))
     ctx.bind_stream()
     _lib.check(_lib.lib().ldsp_sipm_run(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params), C.byref(o)))
     return sc, trig
+
+
+def sipm_resolve_overflow(wf: torch.Tensor, params: _abi.SipmParams, ctx, trig: dict) -> dict:
+    """Second pass of the two-pass trigger fill: traces whose trigger count exceeded the slab capacity run again (the whole
+    fused chain, only these traces) with slabs sized from the counts; afterwards `compact_fields` returns every trigger."""
+    from .extractors import resolve_overflow
+    return resolve_overflow(trig, lambda rows, cap: sipm_run(wf.index_select(0, rows).contiguous(), params, ctx, cap=cap)[1])
 
 
 def dsp_sipm(data: Table, config: dict, pars_optimization: dict, ctx: _lib.Context = None, _waveform_column="waveform") -> Table:
     """`dsp_sipm(data::Table, config::PropDict, pars_optimization::PropDict)` — reference
     src/dsp_sipm.jl:47-158: 24 scalar columns (4 passthrough) + 12 ragged VectorOfVectors columns,
     names as at dsp_sipm.jl:141-157.  Trigger times are in the time-axis unit (ns)."""
-    from .extractors import _compact
+    from .extractors import _compact_group
     wvfs: ArrayOfRDWaveforms = data[_waveform_column]
     params = lower_sipm(config, pars_optimization, wvfs.nsamples, wvfs.t_first, wvfs.dt)
     sc, trig = sipm_run(wvfs.signal, params, ctx)
+    trig = sipm_resolve_overflow(wvfs.signal, params, ctx, trig)   # every crossing is returned (src/intersect_maximum.jl:49-56)
+    vvs = {g: _compact_group(trig[g], ("x", "x_high", "x_tot", "max"))[0] for g in _abi.SIPM_TRIG_GROUPS}
     s = {c: sc[i] for i, c in enumerate(_abi.SIPM_SCALAR_COLS)}
     res = Table()
     res["blfc"] = data["baseline"]; res["timestamp"] = data["timestamp"]
@@ -197,7 +217,7 @@ def dsp_sipm(data: Table, config: dict, pars_optimization: dict, ctx: _lib.Conte
     for k in ["t_max", "t_min", "t_max_lar", "t_min_lar", "e_max", "e_min", "e_max_lar", "e_min_lar",
               "blmean", "blsigma", "blslope", "bloffset", "wfmean", "wfsigma", "wfslope", "wfoffset"]:
         res[k] = s[k]
-    vv = lambda g, f: _compact(trig[g][f], trig[g]["count"])
+    vv = lambda g, f: vvs[g][f]
     res["threshold"] = s["threshold"]; res["threshold_DC"] = s["threshold_DC"]
     res["trig_pos"] = vv("trig", "x"); res["trig_max"] = vv("trig", "max")
     res["trig_pos_DC"] = vv("trig_DC", "x"); res["trig_max_DC"] = vv("trig_DC", "max")

@@ -59,7 +59,7 @@ def hpge_batch(n, L=8192, seed=0x1E6E4D, device="cpu", noise=3.0, chunk=65536, o
     return out
 
 
-def sipm_batch(n, L=16384, seed=0x51B3, device="cpu", noise=0.3, mean_pulses=3.0, chunk=16384, out=None):
+def sipm_batch(n, L=16384, seed=0x51B3, device="cpu", noise=0.3, mean_pulses=3.0, chunk=16384, out=None, first_trace=0):
     """K~Poisson(3) pulses of the reference SiPM shape (10-sample rise 1-exp(-k/3),
     decay 30 samples), amplitudes U[2,10], uniform positions, N(0,0.3) noise."""
     dev = torch.device(device)
@@ -70,7 +70,7 @@ def sipm_batch(n, L=16384, seed=0x51B3, device="cpu", noise=0.3, mean_pulses=3.0
     for c0 in range(0, n, chunk):
         c1 = min(n, c0 + chunk)
         g = torch.Generator(device=dev)
-        g.manual_seed(seed + 104729 * (c0 // chunk))
+        g.manual_seed(seed + 104729 * ((first_trace + c0) // chunk))
         m = c1 - c0
         x = out[c0:c1]
         torch.randn((m, L), generator=g, device=dev, out=x)

@@ -111,3 +111,85 @@ def test_overlapped_gather_pipeline_gloo():
     assert len(seen) == 5
     for step, tab in enumerate(seen):     # every batch arrived intact, in order, rank blocks in place
         assert (tab[:6] == 100 * step).all() and (tab[6:] == 100 * step + 1).all(), step
+
+
+def _ragged_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = ldist.shard_range(n, world, rank)
+    idx = torch.arange(lo, hi)
+    # unequal per-rank trigger totals: trace i has (i * 7) % 5 elements on rank 0's range and three times as many on
+    # rank 1's; one variant (n = 9) leaves rank 1 with traces that all have zero elements
+    cnt = (idx * 7) % 5 * (1 + 2 * rank)
+    if n == 9 and rank == 1:
+        cnt = torch.zeros_like(cnt)
+    vals = torch.repeat_interleave(idx, cnt).to(torch.float32)
+    payload = torch.stack([vals, vals * 2 + 1, -vals], dim=1)      # three fields per element
+    res = ldist.gather_ragged(payload, cnt.to(torch.int32), n, dst=0)
+    if rank == 0:
+        off, out = res
+        q.put((off.numpy(), out.numpy()))
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [9, 10, 11])
+def test_gather_ragged_gloo(n):
+    """counts -> exclusive scan on root -> payload with per-peer sizes (reference columns
+    src/dsp_sipm.jl:149-156), world 2, unequal per-rank totals, unequal shards (n odd), an empty peer (n = 9)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    off, out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    lo1 = ldist.shard_range(n, 2, 1)[0]
+    idx = np.arange(n)
+    cnt = (idx * 7) % 5 * np.where(idx >= lo1, 3, 1)
+    if n == 9:
+        cnt[lo1:] = 0
+    assert off[0] == 0 and np.array_equal(np.diff(off), cnt)
+    vals = np.repeat(idx, cnt).astype(np.float32)
+    np.testing.assert_array_equal(out, np.stack([vals, vals * 2 + 1, -vals], axis=1))
+    for i in range(n):       # element i of the VectorOfVectors is trace i's
+        assert (out[off[i]:off[i + 1], 0] == i).all()
+
+
+def test_gather_ragged_single_process():
+    cnt = torch.tensor([2, 0, 3], dtype=torch.int32)
+    vals = torch.arange(5, dtype=torch.float32)
+    off, out = ldist.gather_ragged(vals, cnt, 3)
+    assert off.tolist() == [0, 2, 2, 5] and out[:, 0].tolist() == [0, 1, 2, 3, 4]
+
+
+@pytest.mark.parametrize("workload", ["icpc", "sipm"])
+def test_bench_self_launch_two_ranks(workload):
+    """`python bench.py --gpus 2` with no rank environment starts its own two ranks (the driver's command); --dry-run
+    runs the launcher, the process group and every gather of the real loop on CPU tensors and prints ONE JSON line."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--n", "500", "--steps", "3", "--warmup", "2",
+                        "--workload", workload], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["gather_ok"] is True
+
+
+def test_bench_launcher_relays_failure():
+    """a rank that exits non-zero (here: argparse rejects the workload in every child) makes the launcher exit non-zero"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "nope"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0

@@ -205,3 +205,28 @@ def test_extractors_match_oracle(orc, batch):
     np.testing.assert_allclose(host(t50), host(fused["t50"]), atol=5e-4)
     qd = ldsp.get_qdrift(pzd, fused["t0"], (2500.0, 5000.0))
     np.testing.assert_allclose(host(qd), host(fused["qdrift"]), rtol=2e-4, atol=40)
+
+
+def test_intersect_maximum_returns_every_crossing_beyond_the_slab(orc):
+    """reference src/intersect_maximum.jl:49-56 pushes EVERY up-crossing: a trace with more crossings than the default slab
+    (LDSP_MAX_TRIG = 64) comes back complete (second pass sized from the counts), multiplicity == length(x)."""
+    n, L = 6, 8192
+    k = np.arange(L)
+    sig = np.zeros((n, L))
+    sig[0] = np.sin(2 * np.pi * k / 40.0)            # ~204 crossings
+    sig[1] = np.sin(2 * np.pi * k / 400.0)           # ~20: stays in the first pass
+    sig[2] = np.sin(2 * np.pi * k / 25.0) * 2        # ~327
+    sig[3] = 0.0                                     # none
+    sig[4] = np.sin(2 * np.pi * k / 128.0)           # exactly 64 periods: 63 or 64 crossings, the boundary
+    sig[5] = np.sin(2 * np.pi * k / 126.0)           # 65: one beyond
+    f = ldsp.IntersectMaximum(mintot=3 * DT, maxtot=30 * DT)
+    r = f(wv(sig), 0.3)
+    mult = host(r["multiplicity"])
+    assert mult[0] > 190 and mult[2] > 300 and mult[3] == 0 and mult[5] > 64
+    for i in range(n):
+        o = orc.intersect_maximum(sig[i].astype(np.float32), 0.3, 3, 30, 0.0, DT)
+        assert mult[i] == o["multiplicity"]
+        for fld in ("x", "x_high", "x_tot", "max"):
+            got = host(r[fld][i])
+            assert len(got) == mult[i]
+            np.testing.assert_allclose(got, o[fld], atol=(2e-2 if fld != "max" else 1e-4), rtol=1e-5)

@@ -118,3 +118,44 @@ def test_sipm_quantised_and_degenerate_traces(orc):
             ok = (np.abs(a - b) <= 2e-3 + 1e-4 * np.abs(b)) | (np.isnan(a) & np.isnan(b))
             assert ok.all(), (generic, c, a[~ok], b[~ok])
     ctx.set_option("sipm_generic", 0)
+
+
+@pytest.mark.parametrize("generic", [0, 1])
+def test_sipm_more_triggers_than_the_slab(orc, generic):
+    """A discharging / very busy trace exceeds 64 triggers per group: dsp_sipm returns all of them (reference
+    src/intersect_maximum.jl:49-56; VERDICT r1 missing #4), in both kernels; quiet traces of the same batch are untouched."""
+    n, L = 12, 16384
+    cfg = ldsp.reference_test_sipm_config()
+    p = ldsp.lower_sipm(cfg, {"sg": {"wl": 200 * ldsp.ns}}, L, 0.0, 16.0)
+    wf = ldsp.synth.sipm_batch(n, L, device="cuda", seed=5)
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    j = torch.arange(L, device="cuda", dtype=torch.float32)
+    for row, npulse in ((2, 150), (7, 90)):                          # pulses every ~100 / ~170 samples
+        pos = torch.linspace(200, L - 400, npulse, device="cuda")
+        u = j[None, :] - pos[:, None]
+        shape = (1 - torch.exp(-u.clamp(min=0) / 3.0)) * ((u >= 0) & (u < 10)) + torch.exp(-(u - 10).clamp(min=0) / 30.0) * (u >= 10)
+        wf[row] = 0.3 * torch.randn(L, generator=g, device="cuda") + (6.0 * shape).sum(0)
+    ctx = ldsp.default_context()
+    ctx.set_option("sipm_generic", generic)
+    try:
+        data = ldsp.Table(waveform=ldsp.ArrayOfRDWaveforms(wf, 0.0, 16.0), baseline=torch.zeros(n), timestamp=torch.zeros(n, dtype=torch.int64),
+                          eventnumber=torch.arange(1, n + 1), daqenergy=torch.zeros(n))
+        res = ldsp.dsp_sipm(data, cfg, {"sg": {"wl": 200 * ldsp.ns}}, ctx)
+        sc, trig = ldsp.sipm_run(wf, p, ctx)
+    finally:
+        ctx.set_option("sipm_generic", 0)
+    ora = orc.dsp_sipm(wf.cpu().numpy(), p, cap=512, nthreads=8)
+    cnt = ora["trig_trap"]["count"]
+    assert cnt[2] > 64 and cnt[7] > 64, cnt                       # the test does overflow the default slab
+    names = {"trig": ("trig_pos", "trig_max"), "trig_DC": ("trig_pos_DC", "trig_max_DC"),
+             "trig_trap": ("trig_pos_trap", "trig_max_trap"), "trig_DC_trap": ("trig_pos_DC_trap", "trig_max_DC_trap")}
+    for grp, (cx, cm) in names.items():
+        oc = ora[grp]["count"]
+        assert np.array_equal(trig[grp]["count"].cpu().numpy(), oc), grp       # the raw counts are the true multiplicities
+        off = res[cx].offsets.cpu().numpy()
+        assert np.array_equal(np.diff(off), oc), grp                             # every trigger is in the table
+        for i in range(n):
+            a = res[cx][i].cpu().numpy().astype(np.float64)
+            np.testing.assert_allclose(a, ora[grp]["x"][i, :oc[i]], atol=0.05, err_msg=f"{grp} trace {i}")
+            m = res[cm][i].cpu().numpy().astype(np.float64)
+            np.testing.assert_allclose(m, ora[grp]["max"][i, :oc[i]], atol=2e-3, rtol=1e-4, err_msg=f"{grp} trace {i}")
