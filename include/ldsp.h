@@ -69,14 +69,8 @@ const char* ldsp_last_error_string(void);
  * then incomplete). */
 int ldsp_ctx_set_option(ldsp_ctx* ctx, const char* key, int64_t value);
 /* sizeof() of the ABI structs as compiled: 0 icpc_params, 1 icpc_out,
- * 2 sipm_params, 3 sipm_out, 4 trig_out (binding self-check). */
+ * 2 sipm_params, 3 sipm_out, 4 trig_out, 5 icpc_opts (binding self-check). */
 int64_t ldsp_abi_sizeof(int which);
-/* dsp_icpc_compressed, windowed traces (src/dsp_icpc.jl:352-353: shift_waveform.(wvfs_wdw, -bl_stats.mean ./ presum_rate)):
- * the following ldsp_icpc_run calls on this context subtract scale * per_trace[i] (device pointer, [n]) instead of the
- * trace's own signalstats(bl_window).mean; blmean then reports that value.  NULL restores the default.
- * Option "icpc_main_only" (ldsp_ctx_set_option) runs dsp_icpc without the CUSP/ZAC stage: e_cusp, e_zac, e_cusp_max,
- * e_zac_max, t_cusp_max, t_zac_max are not written (the windowed traces are shorter than those filters). */
-int ldsp_ctx_set_baseline(ldsp_ctx*, const float* per_trace, double scale);
 /* Average duration in ms of the launches issued by the last ldsp_*_run call,
  * measured with hipEvents recorded on the context stream (timing must have
  * been enabled; synchronises on the closing event). */
@@ -243,6 +237,23 @@ typedef struct {
 /* dsp_icpc(data, config, tau, pars_filter)        src/dsp_icpc.jl:62-230 */
 int ldsp_icpc_run(ldsp_ctx* ctx, const float* wf, int64_t n,
                   const ldsp_icpc_params* p, const ldsp_icpc_out* out);
+
+/* Per-call variations of the chain, passed explicitly (the context carries no per-launch state: like the reference's
+ * immutable functors, a call depends on its arguments only).  Used by dsp_icpc_compressed for the windowed traces
+ * (src/dsp_icpc.jl:352-353: shift_waveform.(wvfs_wdw, -bl_stats.mean ./ presum_rate)):
+ *   ext_baseline != NULL: subtract ext_baseline_scale * ext_baseline[i] (device pointer, [n]) instead of the trace's own
+ *                         signalstats(bl_window).mean; blmean then reports that value.
+ *   main_only != 0:       run without the CUSP/ZAC stage: e_cusp, e_zac, e_cusp_max, e_zac_max, t_cusp_max, t_zac_max are
+ *                         not written (the windowed traces are shorter than those filters).
+ * opts == NULL is ldsp_icpc_run. */
+typedef struct {
+  const float* ext_baseline;
+  double ext_baseline_scale;
+  int32_t main_only;
+  int32_t _pad;
+} ldsp_icpc_opts;
+int ldsp_icpc_run_opts(ldsp_ctx* ctx, const float* wf, int64_t n, const ldsp_icpc_params* p,
+                       const ldsp_icpc_opts* opts, const ldsp_icpc_out* out);
 
 /* ---- "next" row 1: trapezoid filter-optimisation grid scans -----------
  * dsp_trap_rt_optimization (src/dsp_filter_optimization.jl:102-133: pick-off at a fixed

@@ -108,6 +108,11 @@ class SipmParams(C.Structure):
     ]
 
 
+class IcpcOpts(C.Structure):
+    """ldsp_icpc_opts: per-call variations of ldsp_icpc_run_opts (explicit arguments, no context state)."""
+    _fields_ = [("ext_baseline", C.c_void_p), ("ext_baseline_scale", C.c_double), ("main_only", C.c_int32), ("_pad", C.c_int32)]
+
+
 class TrigOut(C.Structure):
     _fields_ = [("count", C.c_void_p), ("x", C.c_void_p), ("x_high", C.c_void_p),
                 ("x_tot", C.c_void_p), ("max", C.c_void_p), ("cap", C.c_int32), ("_pad", C.c_int32)]

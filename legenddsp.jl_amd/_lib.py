@@ -89,7 +89,7 @@ def _declare(lib):
         "ldsp_intersect_maximum": [_VOIDP, _VOIDP, _I64, _I32, _DBL, _DBL, _VOIDP, _I32, _I32, C.POINTER(_abi.TrigOut)],
         "ldsp_multi_intersect": [_VOIDP, _VOIDP, _I64, _I32, _DBL, _DBL, _VOIDP, _I32, _I32, _I32, _I32, _I32, _VOIDP, _VOIDP],
         "ldsp_signal_estimator": [_VOIDP, _VOIDP, _I64, _I32, _DBL, _DBL, _VOIDP, _abi.Dni, _VOIDP],
-        "ldsp_ctx_set_baseline": [_VOIDP, _VOIDP, _DBL],
+        "ldsp_icpc_run_opts": [_VOIDP, _VOIDP, _I64, C.POINTER(_abi.IcpcParams), C.POINTER(_abi.IcpcOpts), C.POINTER(_abi.IcpcOut)],
         "ldsp_qc_features": [_VOIDP, _VOIDP, _I64, _I32, _I32, _I32, _I32, _VOIDP, _VOIDP],
         "ldsp_qc_features_len": [_I32, _I32],
     }
@@ -109,7 +109,7 @@ DECLARED_SYMBOLS = [
     "ldsp_rdfilt_moving_window_multi", "ldsp_rdfilt_affine", "ldsp_cusp_coeffs", "ldsp_zac_coeffs",
     "ldsp_sg_coeffs", "ldsp_signalstats", "ldsp_tailstats", "ldsp_extremestats", "ldsp_thresholdstats",
     "ldsp_thresholdstats_mad", "ldsp_saturation", "ldsp_get_wvf_maximum", "ldsp_intersect",
-    "ldsp_intersect_maximum", "ldsp_multi_intersect", "ldsp_signal_estimator", "ldsp_qc_features", "ldsp_qc_features_len", "ldsp_ctx_set_baseline",
+    "ldsp_intersect_maximum", "ldsp_multi_intersect", "ldsp_signal_estimator", "ldsp_qc_features", "ldsp_qc_features_len", "ldsp_icpc_run_opts",
 ]
 
 
@@ -125,7 +125,7 @@ def lib():
             _declare(l)
             if l.ldsp_abi_version() != _abi.LDSP_ABI_VERSION:
                 raise LdspError(-101, "ABI version mismatch between _abi.py and libldsp_hip.so")
-            for which, st in enumerate((_abi.IcpcParams, _abi.IcpcOut, _abi.SipmParams, _abi.SipmOut, _abi.TrigOut)):
+            for which, st in enumerate((_abi.IcpcParams, _abi.IcpcOut, _abi.SipmParams, _abi.SipmOut, _abi.TrigOut, _abi.IcpcOpts)):
                 if l.ldsp_abi_sizeof(which) != C.sizeof(st):
                     raise LdspError(-102, f"struct size mismatch for {st.__name__}: "
                                           f"{l.ldsp_abi_sizeof(which)} (C) vs {C.sizeof(st)} (ctypes)")
@@ -165,11 +165,6 @@ class Context:
 
     def set_option(self, key, value):
         check(lib().ldsp_ctx_set_option(self._h, key.encode(), int(value)))
-
-    def set_baseline(self, per_trace=None, scale=1.0):
-        """Per-trace baseline (device float32 [n]) for the next icpc_run calls; None restores the traces' own."""
-        ptr = None if per_trace is None else C.c_void_p(per_trace.data_ptr())
-        check(lib().ldsp_ctx_set_baseline(self._h, ptr, float(scale)))
 
     def enable_timing(self, on=True):
         check(lib().ldsp_ctx_enable_timing(self._h, int(on)))

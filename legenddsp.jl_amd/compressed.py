@@ -5,7 +5,7 @@ baseline, tail) and `waveform_windowed` (full sampling rate around the rise: tim
 `decode_data` (LegendDataTypes, :319-320) is the I/O side's codec and stays there: both columns are taken as decoded
 ArrayOfRDWaveforms.  Two launches of the fused kernel (`ldsp_icpc_run`): the presummed traces with parameters lowered for
 their sampling step (rail and SG window scaled by the rate), then the windowed traces — short, with the baseline handed over
-from the presummed ones (`ldsp_ctx_set_baseline`) and without the CUSP/ZAC stage.  `fused_windowed=False` spells the
+from the presummed ones and without the CUSP/ZAC stage (`ldsp_icpc_run_opts`: explicit per-call arguments).  `fused_windowed=False` spells the
 windowed half statement by statement through the filter-functor / extractor entry points instead (the comparator).
 """
 from __future__ import annotations
@@ -34,19 +34,13 @@ WINDOWED_COLS = ("e_max", "e_min", "t0", "t10", "t50", "t80", "t90", "t99", "dri
 def windowed_columns(wdw: ArrayOfRDWaveforms, blmean_pre: torch.Tensor, rate: int, config: DSPConfig, tau: float, pars_filter: dict,
                      ctx: _lib.Context = None) -> dict:
     """The columns `dsp_icpc_compressed` takes from the windowed traces (:352-353, :362-393, :431-435, :452-459), by ONE launch
-    of the fused kernel: baseline = blmean of the presummed trace / rate (`ldsp_ctx_set_baseline`), no CUSP/ZAC stage
-    (option `icpc_main_only`), parameters lowered for the window's own time axis."""
+    of the fused kernel: baseline = blmean of the presummed trace / rate, no CUSP/ZAC stage (both arguments of
+    `ldsp_icpc_run_opts`), parameters lowered for the window's own time axis."""
     x = wdw.signal
     ctx = ctx or _lib.default_context(x.device.index)
     pw = lower_icpc(config, tau, pars_filter, wdw.nsamples, wdw.t_first, wdw.dt, windowed=True)
     bl = blmean_pre.to(device=x.device, dtype=torch.float32).contiguous()
-    ctx.set_baseline(bl, 1.0 / float(rate))
-    ctx.set_option("icpc_main_only", 1)
-    try:
-        B = table_columns(icpc_run(x, pw, ctx))
-    finally:
-        ctx.set_baseline(None)
-        ctx.set_option("icpc_main_only", 0)
+    B = table_columns(icpc_run(x, pw, ctx, ext_baseline=bl, ext_baseline_scale=1.0 / float(rate), main_only=True))
     return {k: B[k] for k in WINDOWED_COLS}
 
 

@@ -121,11 +121,10 @@ struct IcpcDev {
   int32_t dbg_stop;   // profiling aid: return after phase N (0 = run everything)
   const float* h_cusp; // device, true-convolution taps (mode 0)
   const float* h_zac;
-  // dsp_icpc_compressed, windowed traces: baseline handed over from the presummed traces (ext_bl[trace] * ext_bl_scale
-  // replaces signalstats(bl).mean in shift_waveform, src/dsp_icpc.jl:353); NULL = the trace's own baseline
-  const float* ext_bl;
-  float ext_bl_scale;
+  long long* dbg_stamps;   // diagnostic builds (LDSP_STAMPS) only: [LDSP_STAMP_BLOCKS][16 waves][LDSP_STAMP_SLOTS] s_memtime stamps
 };
+#define LDSP_STAMP_BLOCKS 2048
+#define LDSP_STAMP_SLOTS 32
 
 struct IcpcOutDev {
   void* col[LDSP_ICPC_NCOLS];

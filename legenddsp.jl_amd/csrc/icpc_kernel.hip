@@ -25,6 +25,21 @@
 #include "icpc_dev.hpp"
 #include "ldsp_device.hpp"
 
+// LDSP_DEV_512: development builds instantiate the 512-thread kernels only (one fifth of the compile time); the dev
+// library answers LDSP_ERR for other trace lengths.  LDSP_STAMPS: diagnostic build, every wave of the first blocks writes
+// s_memtime at phase boundaries into IcpcDev::dbg_stamps (tools/stamp_map.py); never defined in the shipped library.
+#ifdef LDSP_DEV_512
+#define LDSP_ALL_CASES LDSP_CASE(512)
+#else
+#define LDSP_ALL_CASES LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
+#endif
+#ifdef LDSP_STAMPS
+#define STAMP(id) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < LDSP_STAMP_BLOCKS && P.dbg_stamps) \
+    P.dbg_stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * LDSP_STAMP_SLOTS + (id)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(id) do { } while (0)
+#endif
+
 namespace ldsp {
 
 namespace {
@@ -385,6 +400,7 @@ __device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4
         }
       }
       __syncthreads();
+      STAMP(16);
       // ---- step A1 (LS): flat top + last tap; ZAC: u[n] -> B0 in place
       float ac[SP], dz[SP];
       {
@@ -423,6 +439,7 @@ __device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4
         }
       }
       if (P.dbg_stop == 12) return;
+      STAMP(17);
       // ---- d[i] = (y[i]-y[i-1]) + eps*y[i-1] for 1 <= i < L, else 0   (S4)
       float d[R][4];
 #pragma unroll
@@ -471,6 +488,7 @@ __device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4
         if ((m & 1) == 1) asm volatile("" ::: "memory");
       }
       if (P.dbg_stop == 13) return;
+      STAMP(18);
       // ---- step C: anti-causal one-pole A -> B1, rise(+) and fall(-) exponentials
       {
         float al[R][4], b[R], s_in[R];
@@ -507,6 +525,7 @@ __device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4
         if ((m & 1) == 1) asm volatile("" ::: "memory");
       }
       if (P.dbg_stop == 14) return;
+      STAMP(19);
       if (want_z) {
         // ---- step A2 (S4): PRF = cumsum(cumsum(u)).  Last, when y / d / G / A registers are dead.
         // (u was parked in B0 by step A1; B0 has not been touched since.)  Two levels: inside a
@@ -562,6 +581,7 @@ __device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4
         }
       }
       if (P.dbg_stop == 15) return;
+      STAMP(20);
       float mxc = 0.f, mxz = 0.f;
       if (want_z) {
 #pragma unroll
@@ -573,6 +593,7 @@ __device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4
       if (want_c) finish_locate(0, Lf, ac, mxc);
       if (want_z) finish_locate(1, Lf, dz, mxz);
     }
+    STAMP(21);
     __syncthreads();
     if (WANT_C) finish_collect(0, P.cusp.Lf);
     if (WANT_Z) finish_collect(1, P.zac.Lf);
@@ -650,8 +671,11 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
 // read of the trace, all 48 columns in one row store); otherwise blmean and the t50 position go
 // to `aux` for icpc_cz_kernel.
 template <int NT, int R, bool FULL, bool FUSE>
-__global__ void __launch_bounds__(NT, 4)  // 4 waves/SIMD: <= 128 VGPRs, two 512-thread traces per CU
-icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float* __restrict__ aux, IcpcOutDev out) {
+__global__ void __launch_bounds__(NT, (NT == 1024 && R == 2) ? 8 : 4)  // 4 waves/SIMD: <= 128 VGPRs, two 512-thread traces per CU; <1024, 2>: 8 waves/SIMD, <= 64 VGPRs, two 1024-thread traces per CU
+icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float* __restrict__ aux, IcpcOutDev out,
+            const float* __restrict__ ext_bl, float ext_bl_scale) {
+  // ext_bl: dsp_icpc_compressed, windowed traces: the baseline handed over from the presummed traces (ext_bl[trace] *
+  // ext_bl_scale replaces signalstats(bl).mean in shift_waveform, src/dsp_icpc.jl:353); NULL = the trace's own baseline
   using SM = Smem<NT, R>;
   constexpr int NW = SM::NW, SP = SM::SP, Lp = SM::Lp, NWORDS = SM::NWORDS;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -665,6 +689,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   // results go to the LDS output row as soon as they exist (keeps them out of VGPRs)
   auto put = [&](int c, float v) { if (tid == 0) S.outv[c] = v; };
   auto puti = [&](int c, int v) { if (tid == 0) S.outv[c] = __int_as_float(v); };
+  STAMP(0);
 
   // ------------------------------------------------------------ phase 0: load
   float x[R][4];
@@ -704,6 +729,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       }
       winf_accum4(bl, P.bl, i0, xi0, pv_bl, x[r][0], x[r][1], x[r][2], x[r][3]);
     }
+    STAMP(1);   // trace loaded, raw sums done
     win_publish<NW>(bl, S.wsum, 0);
     rmax = wave_max_all(rmax); rmin = wave_min_all(rmin);
     __syncthreads();  // slots initialised
@@ -713,9 +739,10 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     }
   }
   __syncthreads();
+  STAMP(2);
   // every thread needs the mean; sigma / slope / offset (double divisions, sqrt) only thread 0
   float blmean_ = (float)((double)pv_bl + win_collect1<NW>(S.wsum, 0) * P.bl.inv_n);
-  if (P.ext_bl) blmean_ = P.ext_bl[blockIdx.x] * P.ext_bl_scale;   // windowed traces of dsp_icpc_compressed (dsp_icpc.jl:353)
+  if (ext_bl) blmean_ = ext_bl[blockIdx.x] * ext_bl_scale;   // windowed traces of dsp_icpc_compressed (dsp_icpc.jl:353)
   const float blmean = blmean_;
   if (tid == 0) {
     float m_, blsigma, blslope, bloffset;
@@ -783,6 +810,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   puti(C_n_sat_low_cons, cons_low); puti(C_n_sat_high_cons, cons_high);
   if (P.dbg_stop == 1) return;
 
+  STAMP(3);
   // shift_waveform(-blmean) (dsp_icpc.jl:105); tailstats on the shifted trace
   // (src/tailstats.jl:22-72); cumsum for the pole-zero correction
   double s_off[R];
@@ -826,6 +854,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     }
     S.outv[C_tail_tau] = tail_tau; S.outv[C_tail_mean] = tail_mean; S.outv[C_tail_sigma] = tail_sigma;
   }
+  STAMP(4);
   // InvCRFilter: y = x + c*cumsum(x)  (dsp_icpc.jl:119-120);  x[][] becomes y
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -855,6 +884,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   for (int r = 0; r < R; ++r)
     *reinterpret_cast<float4*>(&S.B0[4 * (tid + NT * r)]) = make_float4(y[r][0], y[r][1], y[r][2], y[r][3]);
   __syncthreads();  // B0 = y visible to every wave (halo and LS reads below)
+  STAMP(5);
   {
     float gmax = -INFINITY;
     WinAccF sgb = {0, 0, 0};   // pivot 0: the SG derivative of a baseline has no level
@@ -955,6 +985,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
         }
       }
     }
+    STAMP(6);   // SG pass done
     win_publish<NW>(sgb, S.wsum, 9);
     gmax = wave_max_all(gmax);
     if (lane == 0) atomicMax(&S.sl->fmx[FX_G], ford(gmax));
@@ -968,6 +999,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     }
   }
   __syncthreads();
+  STAMP(7);
   // get_wvf_maximum (src/interpolation.jl:30-46): parabola through the three samples about the
   // maximum if it is strictly interior.  Wave 0 only; lane 3f+d+1 evaluates filter f at i_f+d.
   if (wave == 0) {
@@ -1004,6 +1036,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       if (bin) *reinterpret_cast<unsigned long long*>(&S.bm[M_INTR * NWORDS + wb]) = bin;
     }
   }
+  STAMP(8);
   // (the run scans of these two masks and the crossing interpolations follow in phase 4b, together with
   //  the seven masks of the sweep: no barrier here — the next one is inside the prefix-sum scan, which
   //  also orders these B1 reads before T overwrites B1)
@@ -1041,6 +1074,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       reinterpret_cast<uint4*>(S.bm)[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
+  STAMP(9);   // T in LDS
   if (tid == 0) {
     float tailmean, tailsigma, tailslope, tailoffset;
     win_finish(win_collect<NW>(S.wsum, 6), P.tail, pv_pz, P.t_first, P.dt, &tailmean, &tailsigma, &tailslope, &tailoffset);
@@ -1130,6 +1164,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
         }
       }
     }
+    STAMP(10);  // sweep A done
     // ---- sweep B: extrema of the three fixed trapezoids and the arg-max of the optimised one
     {
       const float *f0a = tb + f0.n1, *f0b = tb + f0.n1 + f0.g, *f0c = tb + f0.flen;
@@ -1220,6 +1255,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       }
       mx0 *= f0.inv1; mn0 *= f0.inv1; mx1 *= f1.inv1; mx2 *= f2.inv1; mn2 *= f2.inv1; bo_v *= fo.inv1;
     }
+    STAMP(11);  // sweep B done
     mx0 = wave_max_all(mx0); mx1 = wave_max_all(mx1); mx2 = wave_max_all(mx2);
     mn0 = wave_min_all(mn0); mn2 = wave_min_all(mn2);
     unsigned long long bo = wave_max_u64(pack_vi(bo_v, bo_i));
@@ -1236,6 +1272,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   }
   __syncthreads();
   if (P.dbg_stop == 4) return;
+  STAMP(12);
   // Intersect scans on the bit-masks (thread w <-> word w): the seven masks of the sweep and the two
   // of the SG stage (phase 2)
   for (int j = tid; j < 7 * NWORDS; j += NT) {
@@ -1253,6 +1290,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + M_INTR], c); atomicMax(&S.sl->imax[0], f); }
   }
   __syncthreads();
+  STAMP(13);
   // crossing interpolations: wave 0, lanes 0..3 evaluate the four SG samples they need
   if (wave == 0) {
     const int intr_n = S.sl->isum[IS_CNT0 + M_INTR];
@@ -1324,6 +1362,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   }
   if (P.dbg_stop == 5) return;
 
+  STAMP(14);
   // ------------------------------------------------ phase 3c: signal estimators
   // e_trap = SignalEstimator(trap_opt output, t50 + rt + ft/2)     dsp_icpc.jl:163
   // the seven estimates are spread over the waves (each needs a full wave: lane l = window point l)
@@ -1355,6 +1394,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   if (P.dbg_stop == 6) return;
 
 
+  STAMP(15);
   if constexpr (FUSE) {
     // ------------------------------------------- phase 5: CUSP / ZAC (dsp_icpc.jl:167-178)
     // (behind the estimators' barrier: nobody reads the mask words, B1[Lp..] or slots 0..1 any more)
@@ -1371,6 +1411,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       aux[4 * (size_t)blockIdx.x + 2] = ptx[1].fp;
     }
   }
+  STAMP(22);
   // ---------------------------------------------------------------- outputs
   // every S.outv entry was stored by a lane of wave 0 and is read here by wave 0: program order suffices
   static_assert(C_NCOLS <= 64, "the output row is stored by wave 0");
@@ -1607,7 +1648,7 @@ hipError_t launch_trap_grid(const float* wf, int64_t n, int NT, bool full, const
 #define LDSP_CASE(N) \
   case N: return full ? launch_grid_t<N, 4, true>(wf, n, dP, out, st) : launch_grid_t<N, 4, false>(wf, n, dP, out, st);
   switch (NT) {
-    LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
+    LDSP_ALL_CASES
     default: return hipErrorInvalidValue;
   }
 #undef LDSP_CASE
@@ -1790,7 +1831,7 @@ hipError_t launch_fir_grid(const float* wf, int64_t n, int NT, bool full, const 
 #define LDSP_CASE(N) \
   case N: return full ? launch_fir_grid_t<N, 4, true>(wf, n, dP, out, st) : launch_fir_grid_t<N, 4, false>(wf, n, dP, out, st);
   switch (NT) {
-    LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
+    LDSP_ALL_CASES
     default: return hipErrorInvalidValue;
   }
 #undef LDSP_CASE
@@ -1976,7 +2017,7 @@ hipError_t launch_sg_grid(const float* wf, int64_t n, int NT, bool full, const S
     return full ? launch_sg_grid_t<N, 4, true>(wf, n, dP, amax, energy, t50, blm, bls, st)             \
                 : launch_sg_grid_t<N, 4, false>(wf, n, dP, amax, energy, t50, blm, bls, st);
   switch (NT) {
-    LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
+    LDSP_ALL_CASES
     default: return hipErrorInvalidValue;
   }
 #undef LDSP_CASE
@@ -1987,7 +2028,7 @@ constexpr size_t LDS_TWO_PER_CU = 80640;
 
 template <int NT, int R, bool FULL>
 static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
-                                bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st,
+                                const float* ext_bl, float ext_bl_scale, bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st,
                                 hipEvent_t mid, int* stages) {
   using SM = Smem<NT, R>;
   // fused single launch: the normal path (both filters share their geometry, closed form, the gap fits)
@@ -1996,7 +2037,7 @@ static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, f
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_kernel<NT, R, FULL, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_fused);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((icpc_kernel<NT, R, FULL, true>), dim3((unsigned)n), dim3(NT), smem_fused, st, wf, dP, aux, out);
+    hipLaunchKernelGGL((icpc_kernel<NT, R, FULL, true>), dim3((unsigned)n), dim3(NT), smem_fused, st, wf, dP, aux, out, ext_bl, ext_bl_scale);
     *stages = 1;
     return hipGetLastError();
   }
@@ -2004,7 +2045,7 @@ static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, f
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_kernel<NT, R, FULL, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((icpc_kernel<NT, R, FULL, false>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, aux, out);
+  hipLaunchKernelGGL((icpc_kernel<NT, R, FULL, false>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, aux, out, ext_bl, ext_bl_scale);
   e = hipGetLastError();
   *stages = 1;
   if (e == hipSuccess && mid) e = hipEventRecord(mid, st);  // stage boundary for per-kernel timing
@@ -2025,15 +2066,20 @@ static hipError_t launch_icpc_t(const float* wf, int64_t n, const IcpcDev* dP, f
 }
 // `full`: the trace length equals the tile (L == 16*NT), the specialisation without bounds tests.
 // *stages: number of timed stages of this call (1 = fused launch, 2 = icpc_kernel + icpc_cz_kernel)
-hipError_t launch_icpc(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
-                       bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid,
+hipError_t launch_icpc(const float* wf, int64_t n, int NT, int R, bool full, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
+                       const float* ext_bl, float ext_bl_scale, bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid,
                        int* stages) {
+  if (R == 2) {   // 8192 samples on 1024 threads (8 samples per thread)
+    if (NT != 1024) return hipErrorInvalidValue;
+    return full ? launch_icpc_t<1024, 2, true>(wf, n, dP, aux, out, ext_bl, ext_bl_scale, direct, cz_shared, fuse_ok, stop_after_main, cz_pad_floats, st, mid, stages)
+                : launch_icpc_t<1024, 2, false>(wf, n, dP, aux, out, ext_bl, ext_bl_scale, direct, cz_shared, fuse_ok, stop_after_main, cz_pad_floats, st, mid, stages);
+  }
 #define LDSP_CASE(N)                                                                                                                 \
   case N:                                                                                                                            \
-    return full ? launch_icpc_t<N, 4, true>(wf, n, dP, aux, out, direct, cz_shared, fuse_ok, stop_after_main, cz_pad_floats, st, mid, stages) \
-                : launch_icpc_t<N, 4, false>(wf, n, dP, aux, out, direct, cz_shared, fuse_ok, stop_after_main, cz_pad_floats, st, mid, stages);
+    return full ? launch_icpc_t<N, 4, true>(wf, n, dP, aux, out, ext_bl, ext_bl_scale, direct, cz_shared, fuse_ok, stop_after_main, cz_pad_floats, st, mid, stages) \
+                : launch_icpc_t<N, 4, false>(wf, n, dP, aux, out, ext_bl, ext_bl_scale, direct, cz_shared, fuse_ok, stop_after_main, cz_pad_floats, st, mid, stages);
   switch (NT) {
-    LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
+    LDSP_ALL_CASES
     default: return hipErrorInvalidValue;
   }
 #undef LDSP_CASE
@@ -2053,7 +2099,7 @@ hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const I
 #define LDSP_CASE(N) \
   case N: return full ? launch_pz_t<N, 4, true>(wf, n, dP, blmean, e10410, st) : launch_pz_t<N, 4, false>(wf, n, dP, blmean, e10410, st);
   switch (NT) {
-    LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
+    LDSP_ALL_CASES
     default: return hipErrorInvalidValue;
   }
 #undef LDSP_CASE

@@ -16,8 +16,8 @@
 #include "ldsp_ctx.hpp"
 
 namespace ldsp {
-hipError_t launch_icpc(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
-                       bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid,
+hipError_t launch_icpc(const float* wf, int64_t n, int NT, int R, bool full, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
+                       const float* ext_bl, float ext_bl_scale, bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid,
                        int* stages);
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 size_t icpc_smem_bytes(int NT);
@@ -65,6 +65,7 @@ int64_t ldsp_abi_sizeof(int which) {
     case 2: return sizeof(ldsp_sipm_params);
     case 3: return sizeof(ldsp_sipm_out);
     case 4: return sizeof(ldsp_trig_out);
+    case 5: return sizeof(ldsp_icpc_opts);
     default: return -1;
   }
 }
@@ -128,16 +129,10 @@ int ldsp_ctx_set_option(ldsp_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "two_kernel")) { c->two_kernel = value != 0; return LDSP_OK; }
   if (!strcmp(key, "sipm_generic")) { c->sipm_generic = value != 0; return LDSP_OK; }
   if (!strcmp(key, "dbg_stop")) { c->dbg_stop = (int)value; c->icpc_valid = false; return LDSP_OK; }
-  if (!strcmp(key, "icpc_main_only")) { c->icpc_main_only = value != 0; return LDSP_OK; }
+  if (!strcmp(key, "icpc_r2")) { c->icpc_r2 = value != 0; c->icpc_valid = false; return LDSP_OK; }
+  if (!strcmp(key, "dbg_stamps")) { c->dbg_stamps = reinterpret_cast<long long*>((uintptr_t)value); c->icpc_valid = false; return LDSP_OK; }
   if (!strcmp(key, "fir_grid_per_point")) { c->fir_grid_per_point = value != 0; return LDSP_OK; }
   return fail(LDSP_ERR_INVALID_ARG, "unknown option '%s'", key);
-}
-
-int ldsp_ctx_set_baseline(ldsp_ctx* c, const float* per_trace, double scale) {
-  if (!c) return fail(LDSP_ERR_INVALID_ARG, "ctx is NULL");
-  c->ext_bl = per_trace; c->ext_bl_scale = (float)scale;
-  c->icpc_valid = false;   // the device parameter block carries the pointer
-  return LDSP_OK;
 }
 
 int ldsp_ctx_enable_timing(ldsp_ctx* c, int on) {
@@ -269,7 +264,7 @@ static bool make_cuspzac(const ldsp_cuspzac& p, bool zac, CuspZacDev& d) {
   return true;
 }
 
-static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, IcpcDev& d, std::vector<float>& hc, std::vector<float>& hz) {
+static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, int r2, IcpcDev& d, std::vector<float>& hc, std::vector<float>& hz) {
   memset(&d, 0, sizeof d);
   const int L = p.L;
   if (L < 64 || L > LDSP_MAX_L) return fail(LDSP_ERR_UNSUPPORTED, "trace length %d outside [64, %d]", L, LDSP_MAX_L);
@@ -279,7 +274,7 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, IcpcDev& d
   if (L <= 1024) { d.NT = 64; d.R = 4; }
   else if (L <= 2048) { d.NT = 128; d.R = 4; }
   else if (L <= 4096) { d.NT = 256; d.R = 4; }
-  else if (L <= 8192) { d.NT = 512; d.R = 4; }
+  else if (L <= 8192) { d.NT = 512; d.R = 4; if (r2) { d.NT = 1024; d.R = 2; } }
   else if (L <= 16384) { d.NT = 1024; d.R = 4; }
   else return fail(LDSP_ERR_UNSUPPORTED, "dsp_icpc kernel keeps the trace in LDS: L <= 16384 (got %d)", L);
   d.t_first = (float)p.t_first; d.dt = (float)p.dt;
@@ -351,11 +346,11 @@ static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p) {
   if (c->icpc_valid && c->icpc_mode_built == c->cusp_direct && !memcmp(&c->icpc_last, p, sizeof *p)) return LDSP_OK;
   std::vector<float> hc, hz;
   IcpcDev d;
-  int rc = lower_icpc_dev(*p, c->cusp_direct, d, hc, hz);
+  int rc = lower_icpc_dev(*p, c->cusp_direct, c->icpc_r2, d, hc, hz);
   if (rc) return rc;
   d.h_cusp = c->d_hc; d.h_zac = c->d_hz;
   d.dbg_stop = c->dbg_stop;
-  d.ext_bl = c->ext_bl; d.ext_bl_scale = c->ext_bl_scale;
+  d.dbg_stamps = c->dbg_stamps;
   c->icpc_host = d;
   HIP_TRY(hipMemcpyAsync(c->d_icpc, &c->icpc_host, sizeof(IcpcDev), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_hc, hc.data(), sizeof(float) * hc.size(), hipMemcpyHostToDevice, c->stream));
@@ -368,7 +363,15 @@ static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p) {
 extern "C" {
 
 int ldsp_icpc_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_params* p, const ldsp_icpc_out* out) {
+  return ldsp_icpc_run_opts(c, wf, n, p, nullptr, out);
+}
+
+int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_params* p, const ldsp_icpc_opts* opts,
+                       const ldsp_icpc_out* out) {
   if (!c || !p || !out) return fail(LDSP_ERR_INVALID_ARG, "ldsp_icpc_run: NULL argument");
+  const bool main_only = opts && opts->main_only != 0;
+  const float* ext_bl = opts ? opts->ext_baseline : nullptr;
+  const float ext_bl_scale = opts ? (float)opts->ext_baseline_scale : 1.f;
   if (n < 0 || n > 0x7fffffffLL) return fail(LDSP_ERR_INVALID_ARG, "n = %lld out of range", (long long)n);
   if (n == 0) return LDSP_OK;
   if (!wf) return fail(LDSP_ERR_INVALID_ARG, "waveform pointer is NULL");
@@ -388,9 +391,9 @@ int ldsp_icpc_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_param
   }
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   int stages = 1;
-  HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->icpc_host.L == 16 * c->icpc_host.NT, c->d_icpc, c->d_aux, od, c->icpc_host.cusp_mode == 0,
-                      c->icpc_host.cz_shared != 0, !c->two_kernel && !c->icpc_main_only,
-                      c->icpc_main_only || (c->dbg_stop > 0 && c->dbg_stop < 10),
+  HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->icpc_host.R, c->icpc_host.L == 4 * c->icpc_host.R * c->icpc_host.NT, c->d_icpc, c->d_aux, od, ext_bl, ext_bl_scale,
+                      c->icpc_host.cusp_mode == 0, c->icpc_host.cz_shared != 0, !c->two_kernel && !main_only,
+                      main_only || (c->dbg_stop > 0 && c->dbg_stop < 10),
                       ((std::max(c->icpc_host.cusp.Lf, c->icpc_host.zac.Lf) + 2 + 7) & ~3), c->stream,
                       c->timing ? c->evm : nullptr, &stages));
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = stages; }
@@ -406,7 +409,8 @@ int ldsp_icpc_pz_trap_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_ic
   int rc = prepare_icpc(c, p);
   if (rc) return rc;
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  HIP_TRY(launch_pz_trap(wf, n, c->icpc_host.NT, c->icpc_host.L == 16 * c->icpc_host.NT, c->d_icpc, blmean, e_10410, c->stream));
+  const int nt_pz = c->icpc_host.R == 2 ? 512 : c->icpc_host.NT;   // pz_trap_kernel keeps 16 samples per thread
+  HIP_TRY(launch_pz_trap(wf, n, nt_pz, c->icpc_host.L == 16 * nt_pz, c->d_icpc, blmean, e_10410, c->stream));
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
   return LDSP_OK;
 }

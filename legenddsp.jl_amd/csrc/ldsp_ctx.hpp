@@ -37,10 +37,9 @@ struct ldsp_ctx {
   int sipm_generic = 0; // option "sipm_generic": always the generic two-array dsp_sipm kernel
   int two_kernel = 0;   // option "two_kernel": never fuse the CUSP/ZAC stage into icpc_kernel
   int dbg_stop = 0;
+  int icpc_r2 = 0;      // option "icpc_r2": 4097..8192-sample traces on 1024 threads x 8 samples (8 waves per SIMD) instead of 512 x 16
+  long long* dbg_stamps = nullptr;   // option "dbg_stamps": device buffer of a diagnostic (LDSP_STAMPS) build
   int fir_grid_per_point = 0;    // option "fir_grid_per_point": ldsp_fir_grid_run evaluates every grid point's filter outputs (comparator)
-  int icpc_main_only = 0;        // option "icpc_main_only": dsp_icpc without the CUSP/ZAC stage (its six columns are not written)
-  const float* ext_bl = nullptr; // ldsp_ctx_set_baseline: per-trace baseline for the next ldsp_icpc_run calls
-  float ext_bl_scale = 1.f;
   // timing
   int timing = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;  // evm: boundary between the two dsp_icpc kernels

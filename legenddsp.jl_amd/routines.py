@@ -59,11 +59,15 @@ def _as_device_f32(x: torch.Tensor, device) -> torch.Tensor:
     return x
 
 
-def icpc_run(wf: torch.Tensor, params: _abi.IcpcParams, ctx: _lib.Context = None, out: torch.Tensor = None) -> torch.Tensor:
+def icpc_run(wf: torch.Tensor, params: _abi.IcpcParams, ctx: _lib.Context = None, out: torch.Tensor = None,
+             ext_baseline: torch.Tensor = None, ext_baseline_scale: float = 1.0, main_only: bool = False) -> torch.Tensor:
     """Run the fused kernel on a device-resident [n, L] float32 batch.
 
     Returns the [n, 48] float32 output table (columns in `_abi.ICPC_COLS` order;
-    the 5 integer columns hold int32 bit patterns — see `table_columns`)."""
+    the 5 integer columns hold int32 bit patterns — see `table_columns`).
+    `ext_baseline` (device float32 [n]) x `ext_baseline_scale` replaces the traces' own baseline mean and `main_only`
+    skips the CUSP/ZAC stage (`ldsp_icpc_run_opts`; what dsp_icpc_compressed needs for its windowed traces) — per-call
+    arguments, the context keeps no state between calls."""
     if not wf.is_cuda:
         raise _lib.LdspError(-103, "icpc_run needs a device-resident waveform tensor (no CPU fallback)")
     ctx = ctx or _lib.default_context(wf.device.index)
@@ -74,14 +78,21 @@ def icpc_run(wf: torch.Tensor, params: _abi.IcpcParams, ctx: _lib.Context = None
     nc = len(_abi.ICPC_COLS)
     if out is None:
         out = torch.empty((n, nc), dtype=torch.float32, device=wf.device)
-    assert out.shape == (n, nc) and out.is_contiguous() and out.dtype == torch.float32
+    if out.shape != (n, nc) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != wf.device:
+        raise ValueError(f"out must be a contiguous float32 [{n}, {nc}] tensor on the waveforms' device")
     o = _abi.IcpcOut()
     base = out.data_ptr()
     for i, c in enumerate(_abi.ICPC_COLS):
         setattr(o, c, base + 4 * i)
     o.stride = nc
+    opts = None
+    if ext_baseline is not None or main_only:
+        if ext_baseline is not None and (ext_baseline.shape != (n,) or ext_baseline.dtype != torch.float32 or ext_baseline.device != wf.device
+                                         or not ext_baseline.is_contiguous()):
+            raise ValueError("ext_baseline must be a contiguous float32 [n] tensor on the waveforms' device")
+        opts = C.byref(_abi.IcpcOpts(None if ext_baseline is None else ext_baseline.data_ptr(), float(ext_baseline_scale), int(bool(main_only)), 0))
     ctx.bind_stream()
-    _lib.check(_lib.lib().ldsp_icpc_run(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params), C.byref(o)))
+    _lib.check(_lib.lib().ldsp_icpc_run_opts(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params), opts, C.byref(o)))
     return out
 
 
@@ -91,8 +102,13 @@ def icpc_pz_trap_run(wf: torch.Tensor, params: _abi.IcpcParams, ctx: _lib.Contex
         raise _lib.LdspError(-103, "needs a device-resident waveform tensor (no CPU fallback)")
     ctx = ctx or _lib.default_context(wf.device.index)
     n, L = wf.shape
+    if L != params.L:
+        raise ValueError(f"waveform length {L} != params.L {params.L}")
+    wf = _as_device_f32(wf, wf.device)
     if out is None:
         out = torch.empty((2, n), dtype=torch.float32, device=wf.device)
+    if out.shape != (2, n) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != wf.device:
+        raise ValueError(f"out must be a contiguous float32 [2, {n}] tensor on the waveforms' device")
     ctx.bind_stream()
     _lib.check(_lib.lib().ldsp_icpc_pz_trap_run(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params),
                                                 C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr())))

@@ -1,0 +1,43 @@
+"""A/B timing + parity check of dsp_icpc variants in ONE process (interleaved rounds; cdna_hip_programming.md rule 24).
+usage: python tools/dev_time.py [n] [opt=val ...]   e.g.  python tools/dev_time.py 65536 icpc_r2=1
+Runs the fused kernel with the default options and with the given options alternately (5 rounds), prints min / median
+kernel ms of both, and the parity of the variant against the oracle on the first 512 traces."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+import legenddsp_jl_amd as ldsp
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 and "=" not in sys.argv[1] else 65536
+opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+L = 8192
+p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, L, 0.0, 16.0)
+wf = ldsp.synth.hpge_batch(n, L, device="cuda")
+ctx = ldsp.Context(0); ctx.enable_timing(True)
+out = torch.empty((n, 48), dtype=torch.float32, device="cuda")
+
+def setopts(on):
+    for k, v in opts.items():
+        ctx.set_option(k, int(v) if on else 0)
+
+ts = {False: [], True: []}
+for rnd in range(6):
+    for on in ((False, True) if opts else (False,)):
+        setopts(on)
+        ldsp.icpc_run(wf, p, ctx, out=out)
+        if rnd:
+            ts[on].append(ctx.last_kernel_ms())
+for on in ((False, True) if opts else (False,)):
+    t = np.array(ts[on])
+    print(f"{'variant ' + str(opts) if on else 'default':40s} min {t.min():.3f} ms  median {np.median(t):.3f} ms  -> {n / t.min() * 1e-3:.2f} M waveforms/s")
+# parity of the last configuration run
+from oracle import oracle as orc
+import parity
+m = min(n, 512)
+g = {k: v[:m].cpu().numpy() for k, v in ldsp.table_columns(out).items()}
+o = orc.dsp_icpc(wf[:m].cpu().numpy(), p, nthreads=16)
+lines, worst = parity.compare(g, o)
+bad = [l for l in lines if not l.rstrip().endswith(" 0")]
+print(f"parity vs oracle on {m} traces: worst bad fraction {worst:.4f}")
+if worst > 0:
+    print("\n".join(lines))

@@ -1,0 +1,42 @@
+"""Timeline of the fused dsp_icpc kernel from in-kernel s_memtime stamps (diagnostic build: tools/dev_build.sh stamps
+-DLDSP_STAMPS; run with LDSP_HIP_LIB=build/dev/libldsp_stamps.so).  Per phase (interval between two stamps): mean cycles
+a wave spends in it, the part of it that is waiting for the slowest wave of the workgroup (arrival spread at the stamp
+that ends the phase), and the share of the trace's lifetime.  usage: python tools/stamp_map.py [n_traces]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import legenddsp_jl_amd as ldsp
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+L, NW, SLOTS, BLOCKS = 8192, 8, 32, 2048
+params = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, L, 0.0, 16.0)
+wf = ldsp.synth.hpge_batch(n, L, device="cuda")
+ctx = ldsp.Context(0)
+buf = torch.zeros((BLOCKS, 16, SLOTS), dtype=torch.int64, device="cuda")
+out = torch.empty((n, 48), dtype=torch.float32, device="cuda")
+ldsp.icpc_run(wf, params, ctx, out=out)          # warm-up without stamps
+ctx.set_option("dbg_stamps", buf.data_ptr())
+ldsp.icpc_run(wf, params, ctx, out=out)
+torch.cuda.synchronize()
+ctx.set_option("dbg_stamps", 0)
+s = buf.cpu().numpy()[:, :NW, :].astype(np.float64)     # [block, wave, slot]
+names = {0: "start", 1: "load + raw sums", 2: "bl reduce + barrier", 3: "blmean, saturation", 4: "shift, tail logs, cumsum scan",
+         5: "pz + y -> LDS + barrier", 6: "SG pass", 7: "SG reductions + barrier", 8: "wvf maxima, SG masks", 9: "T scan + T -> LDS + barrier",
+         10: "sweep A (7 masks)", 11: "sweep B (4 trapezoids)", 12: "sweep reductions + barrier", 13: "run scans + barrier",
+         14: "crossings", 15: "estimators + barrier", 16: "CZ: Dp (+barrier)", 17: "CZ: flat top + ZAC taps", 18: "CZ: d, causal scan + readback",
+         19: "CZ: anti-causal scan + readback", 20: "CZ: double cumsum + readback", 21: "CZ: finish", 22: "CZ: collect"}
+ids = sorted(names)
+valid = (s[:, :, ids] > 0).all(axis=(1, 2))
+s = s[valid]
+print(f"{valid.sum()} of {BLOCKS} stamped workgroups complete; cycles per wave (mean over waves and workgroups)")
+life = (s[:, :, ids[-1]].max(axis=1) - s[:, :, ids[0]].min(axis=1)).mean()
+tot = 0.0
+print(f"{'phase':42s} {'mean':>8s} {'wait':>8s} {'share':>7s}")
+for a, b in zip(ids[:-1], ids[1:]):
+    d = (s[:, :, b] - s[:, :, a]).mean()
+    # time the average wave then waits for the slowest one of its workgroup at the end of this phase
+    spread = (s[:, :, b].max(axis=1, keepdims=True) - s[:, :, b]).mean()
+    tot += d
+    print(f"{names[b]:42s} {d:8.0f} {spread:8.0f} {100 * d / life:6.1f}%")
+print(f"{'workgroup lifetime (first start -> last end)':42s} {life:8.0f}")
