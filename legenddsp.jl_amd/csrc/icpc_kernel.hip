@@ -869,6 +869,36 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   }
   auto& y = x;
   if (P.dbg_stop == 7) return;
+  // get_threshold at 10 / 50 / 80 / 90 / 99 % of the pre-PZ maximum (dsp_icpc.jl:132-136): Intersect needs the FIRST up-crossing
+  // that holds for tx_mintot samples, and on a pulse that is the first sample at or above the threshold.  Each thread
+  // finds that sample among its own 16 (S4 view, registers: a compare + select per sample and threshold, no ballots, no
+  // mask words), the workgroup takes the minimum; the candidate is confirmed further down (the samples after it, and that
+  // it is not sample 0) and only a trace that fails the confirmation runs the general bit-mask scan.
+  const float thr_tx[5] = {e_max * 0.1f, e_max * 0.5f, e_max * 0.8f, e_max * 0.9f, e_max * 0.99f};
+  if (e_max > 0.f) {   // thresholds ascend; otherwise the general scan handles the trace
+    auto first_code = [&](float thr) {   // 4r+e of the thread's first sample >= thr, 16 = none  (y is 0 beyond L, thr > 0)
+      int code = 16;
+#pragma unroll
+      for (int r = R - 1; r >= 0; --r)
+#pragma unroll
+        for (int e = 3; e >= 0; --e) code = (y[r][e] < thr) ? code : (4 * r + e);
+      return code;
+    };
+    int code[5];
+    code[0] = first_code(thr_tx[0]);
+    code[4] = first_code(thr_tx[4]);
+    if (__ballot(code[0] != code[4]) == 0ull) {   // wave-uniform: no sample of this wave lies between the lowest and the highest threshold
+      code[1] = code[2] = code[3] = code[0];
+    } else {
+      code[1] = first_code(thr_tx[1]); code[2] = first_code(thr_tx[2]); code[3] = first_code(thr_tx[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const uint32_t key = (code[q] == 16) ? 0x7fffffffu : (uint32_t)(4 * (tid + NT * (code[q] >> 2)) + (code[q] & 3));
+      const uint32_t kmin = wave_min_u32(key);
+      if (lane == 0 && kmin != 0x7fffffffu) atomicMin(&S.sl->imin[q], (int)kmin);
+    }
+  }
 
   // ----------------------------------- phase 2: SG derivatives, current maxima
   // (runs before the prefix sum T is built: its full-length output is parked in B1, which T then
@@ -1026,15 +1056,34 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     if (thr_intr == 0.f) thr_intr = 1.f;
     thr_sg50 = ford_inv(S.sl->fmx[FX_G]) * 0.5f;
   }
+  // t50_current (dsp_icpc.jl:192-195) is the first up-crossing of thr_sg50 held for tx_mintot samples.  With tx_mintot = 2
+  // (the usual 32 ns at 16 ns sampling) a crossing at k is  g[k-1] < thr <= min(g[k], g[k+1]):  three reads per sample and a
+  // running select give each thread its first crossing, no ballot and no mask words; other values of tx_mintot take the
+  // bit-mask scan.  The in-trace pile-up mask (a count of runs is needed there) stays a ballot per row.
+  const bool sg50_direct = P.tx_mintot == 2;   // block-uniform
+  int code50 = SP;
 #pragma unroll
-  for (int m = 0; m < SP; ++m) {
-    const float g = S.B1[tid + NT * m];  // LS view of the SG output
-    const unsigned long long b50 = __ballot(g >= thr_sg50), bin = __ballot(g >= thr_intr);
+  for (int m = SP - 1; m >= 0; --m) {
+    const float g = S.B1[tid + NT * m];  // LS view of the SG output (-inf beyond its last sample)
+    if (sg50_direct) {
+      float gm = S.B1[max(tid + NT * m - 1, 0)];
+      const float gp = S.B1[tid + NT * m + 1];
+      if (m == 0) gm = (tid == 0) ? INFINITY : gm;            // a run that starts the trace is no crossing
+      const float w = (gm < thr_sg50) ? vmin(g, gp) : -INFINITY;
+      code50 = (w >= thr_sg50) ? m : code50;
+    }
+    const unsigned long long bin = __ballot(g >= thr_intr);
+    unsigned long long b50 = 0ull;
+    if (!sg50_direct) b50 = __ballot(g >= thr_sg50);
     if (lane == 0) {  // words were zeroed before the SG pass: only non-zero ballots are stored
       const int wb = (NT >> 5) * m + 2 * wave;
       if (b50) *reinterpret_cast<unsigned long long*>(&S.bm[M_SG50 * NWORDS + wb]) = b50;
       if (bin) *reinterpret_cast<unsigned long long*>(&S.bm[M_INTR * NWORDS + wb]) = bin;
     }
+  }
+  if (sg50_direct) {
+    const uint32_t kmin = wave_min_u32(code50 == SP ? 0x7fffffffu : (uint32_t)(tid + NT * code50));
+    if (lane == 0 && kmin != 0x7fffffffu) atomicMin(&S.sl->imin[M_SG50], (int)kmin);
   }
   STAMP(8);
   // (the run scans of these two masks and the crossing interpolations follow in phase 4b, together with
@@ -1070,8 +1119,9 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     }
     win_publish<NW>(pz, S.wsum, 6);
     if (tid == 0) S.B1[Lp] = (float)tot_all;  // T[Lp] (= T[L] when L == Lp; y is 0 beyond L)
-    for (int i = tid; i < 7 * NWORDS / 4; i += NT)  // phase-3 mask words: only non-zero ballots are stored
-      reinterpret_cast<uint4*>(S.bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    static_assert(M_T0INV == M_T0 + 1, "mask order");
+    for (int i = tid; i < 2 * NWORDS / 4; i += NT)  // mask words of the t0 trapezoid: only non-zero ballots are stored
+      reinterpret_cast<uint4*>(S.bm + M_T0 * NWORDS)[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
   STAMP(9);   // T in LDS
@@ -1083,7 +1133,6 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   if (P.dbg_stop == 3) return;
 
   // ------------------------------------------------ phase 4: lane-strided sweep
-  const float thr_tx[5] = {e_max * 0.1f, e_max * 0.5f, e_max * 0.8f, e_max * 0.9f, e_max * 0.99f};
   {
     float mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY, mn0 = INFINITY, mn2 = INFINITY;
     float bo_v = -INFINITY; int bo_i = 0x7fffffff;
@@ -1100,29 +1149,21 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     auto traw = [&](const float* a, const float* b, const float* c, float rr, float Tk, int m) {
       return fmaf(c[NT * m] - b[NT * m], rr, -(a[NT * m] - Tk));
     };
-    // ---- sweep A: threshold bit-masks of y (5) and of the t0 trapezoid (2)
+    // ---- sweep A: threshold bit-masks of the t0 trapezoid (t0, inverted t0).  (The five thresholds on y are found from
+    // registers, see the candidate search after the pole-zero stage.)
     {
-      const float* yb = &S.B0[tid];
       const float *t0a = tb + t0.n1, *t0b = tb + t0.n1 + t0.g, *t0c = tb + t0.flen;
       const float *tia = tb + t0i.n1, *tib = tb + t0i.n1 + t0i.g, *tic = tb + t0i.flen;
       const float rr0 = t0.rr, rri = t0i.rr;
       const float thr0 = P.t0_thr * t0.navg, thr0i = -P.t0_thr * t0i.navg;
-      // ballots of one row and the stores of the non-zero ones.  The mask words were zeroed in phase 2: all-zero ballots
-      // (most rows of the t0 masks, the baseline rows of the y masks) are not stored.  thr_tx ascends, so bq[0] covers bq[1..4].
-      auto emit = [&](int m, float yv, float o0, float o0i) {
-        unsigned long long bq[7];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) bq[q] = __ballot(yv >= thr_tx[q]);
-        bq[M_T0] = __ballot(o0 >= thr0);
-        bq[M_T0INV] = __ballot(o0i <= thr0i);   // -trap >= thr
+      // ballots of one row and the stores of the non-zero ones (the mask words were zeroed in phase 3)
+      auto emit = [&](int m, float o0, float o0i) {
+        const unsigned long long b0 = __ballot(o0 >= thr0);
+        const unsigned long long bi = __ballot(o0i <= thr0i);   // -trap >= thr
         if (lane == 0) {
           const int wb = (NT >> 5) * m + 2 * wave;
-          if (bq[0] | (e_max <= 0.f ? ~0ull : 0ull)) {
-#pragma unroll
-            for (int q = 0; q < 5; ++q) *reinterpret_cast<unsigned long long*>(&S.bm[q * NWORDS + wb]) = bq[q];
-          }
-          if (bq[M_T0]) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0 * NWORDS + wb]) = bq[M_T0];
-          if (bq[M_T0INV]) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0INV * NWORDS + wb]) = bq[M_T0INV];
+          if (b0) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0 * NWORDS + wb]) = b0;
+          if (bi) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0INV * NWORDS + wb]) = bi;
         }
       };
       static_assert(SP % 4 == 0, "row groups");
@@ -1132,10 +1173,10 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
         if (NT * (m0 + 4) <= nout_grp) {
           // four rows wholly inside the trace and both output ranges: all their reads go out before the first comparison
           // (compiler fence), the LDS latency is paid once per group
-          float yv[4], tk[4], ra[4], rb[4], rc[4], ia[4], ib[4], ic[4];
+          float tk[4], ra[4], rb[4], rc[4], ia[4], ib[4], ic[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            yv[q] = yb[NT * (m0 + q)]; tk[q] = tb[NT * (m0 + q)];
+            tk[q] = tb[NT * (m0 + q)];
             ra[q] = t0a[NT * (m0 + q)]; rb[q] = t0b[NT * (m0 + q)]; rc[q] = t0c[NT * (m0 + q)];
             if (!inv_same) { ia[q] = tia[NT * (m0 + q)]; ib[q] = tib[NT * (m0 + q)]; ic[q] = tic[NT * (m0 + q)]; }
           }
@@ -1144,15 +1185,13 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
           for (int q = 0; q < 4; ++q) {
             const float o0 = fmaf(rc[q] - rb[q], rr0, -(ra[q] - tk[q]));
             const float o0i = inv_same ? o0 : fmaf(ic[q] - ib[q], rri, -(ia[q] - tk[q]));
-            emit(m0 + q, yv[q], o0, o0i);
+            emit(m0 + q, o0, o0i);
           }
           continue;
         }
 #pragma unroll
         for (int m = m0; m < m0 + 4; ++m) {
           const int k = tid + NT * m;
-          float yv = yb[NT * m];
-          if (!FULL && NT * (m + 1) > L) yv = (k < L) ? yv : -INFINITY;
           const float Tk = tb[NT * m];
           float o0 = NAN, o0i = NAN;   // NaN: both comparisons false for rows/lanes outside the output range
           if (NT * (m + 1) <= nout_t0) o0 = traw(t0a, t0b, t0c, rr0, Tk, m);
@@ -1160,7 +1199,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
           if (inv_same) o0i = o0;
           else if (NT * (m + 1) <= nout_t0i) o0i = traw(tia, tib, tic, rri, Tk, m);
           else if (NT * m < nout_t0i) { o0i = traw(tia, tib, tic, rri, Tk, m); o0i = (k < nout_t0i) ? o0i : NAN; }
-          emit(m, yv, o0, o0i);
+          emit(m, o0, o0i);
         }
       }
     }
@@ -1273,19 +1312,20 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   __syncthreads();
   if (P.dbg_stop == 4) return;
   STAMP(12);
-  // Intersect scans on the bit-masks (thread w <-> word w): the seven masks of the sweep and the two
+  // Intersect scans on the bit-masks (thread w <-> word w): the two masks of the sweep and the two
   // of the SG stage (phase 2)
-  for (int j = tid; j < 7 * NWORDS; j += NT) {
-    const int q = j / NWORDS, wd = j - q * NWORDS;
-    const int min_n = (q < 5) ? P.tx_mintot : P.t0_mintot;
+  for (int j = tid; j < 2 * NWORDS; j += NT) {
+    const int q = M_T0 + j / NWORDS, wd = j % NWORDS;
     int c, f;
-    intersect_word(S.bm + q * NWORDS, wd, NWORDS, min_n, &c, &f);
+    intersect_word(S.bm + q * NWORDS, wd, NWORDS, P.t0_mintot, &c, &f);
     if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + q], c); atomicMin(&S.sl->imin[q], f); }
   }
   for (int wd = tid; wd < NWORDS; wd += NT) {
     int c, f;
-    intersect_word(S.bm + M_SG50 * NWORDS, wd, NWORDS, P.tx_mintot, &c, &f);
-    if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + M_SG50], c); atomicMin(&S.sl->imin[M_SG50], f); }
+    if (P.tx_mintot != 2) {   // otherwise found without a mask (phase 2)
+      intersect_word(S.bm + M_SG50 * NWORDS, wd, NWORDS, P.tx_mintot, &c, &f);
+      if (c) atomicMin(&S.sl->imin[M_SG50], f);
+    }
     intersect_word_rev(S.bm + M_INTR * NWORDS, wd, NWORDS, ng, P.intrace_mintot, &c, &f);
     if (c) { atomicAdd(&S.sl->isum[IS_CNT0 + M_INTR], c); atomicMax(&S.sl->imax[0], f); }
   }
@@ -1294,8 +1334,8 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   // crossing interpolations: wave 0, lanes 0..3 evaluate the four SG samples they need
   if (wave == 0) {
     const int intr_n = S.sl->isum[IS_CNT0 + M_INTR];
-    const bool has50 = S.sl->isum[IS_CNT0 + M_SG50] > 0;
     const int p = S.sl->imin[M_SG50], e = S.sl->imax[0];
+    const bool has50 = p != 0x7fffffff;
     const int at = (lane == 0) ? p - 1 : (lane == 1) ? p : (lane == 2) ? e + 1 : e;
     float ev = 0.f;
     if (lane < 4 && ((lane < 2) ? has50 : intr_n > 0)) ev = flt_rare(0, at);
@@ -1322,6 +1362,43 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
     // trap(-y) = -trap(y)  (dsp_icpc.jl:199-204)
     put(C_e_10410_inv, ford_inv(S.sl->fmx[FX_F0I])); put(C_e_313_inv, ford_inv(S.sl->fmx[FX_F2I]));
   }
+  // Confirmation of the five threshold candidates (imin[0..4] = first sample at or above the threshold): a candidate is the
+  // crossing Intersect reports if it is not sample 0 (a run that starts the trace is no crossing) and the tx_mintot - 1 samples
+  // after it stay at or above the threshold.  Every wave checks all five (lane q <-> threshold q) and reaches the same
+  // verdict; a trace that fails (e.g. a noise spike in front of the pulse) — or whose thresholds do not ascend — runs the
+  // general scan: bit-masks of y by ballot, run scan on the words (reference scan: src/intersect_maximum.jl:41-56).
+  {
+    const int q = min(lane, 4);
+    const int p = S.sl->imin[q];
+    bool ok = e_max > 0.f;
+    if (ok && p != 0x7fffffff) {
+      const float thrq = e_max * ((q == 0) ? 0.1f : (q == 1) ? 0.5f : (q == 2) ? 0.8f : (q == 3) ? 0.9f : 0.99f);   // = thr_tx[q]
+      ok = p >= 1 && p + P.tx_mintot <= L;
+      for (int j = 1; ok && j < P.tx_mintot; ++j) ok = S.B0[p + j] >= thrq;
+    }
+    if (__ballot(lane < 5 && !ok) != 0ull) {   // block-uniform
+      __syncthreads();                          // every wave has read the candidates
+      if (tid < 5) S.sl->imin[tid] = 0x7fffffff;
+      for (int m = 0; m < SP; ++m) {
+        const int k = tid + NT * m;
+        float yv = S.B0[k];
+        if (!FULL) yv = (k < L) ? yv : -INFINITY;
+#pragma unroll
+        for (int qq = 0; qq < 5; ++qq) {
+          const unsigned long long b = __ballot(yv >= thr_tx[qq]);
+          if (lane == 0) *reinterpret_cast<unsigned long long*>(&S.bm[qq * NWORDS + (NT >> 5) * m + 2 * wave]) = b;
+        }
+      }
+      __syncthreads();
+      for (int j = tid; j < 5 * NWORDS; j += NT) {
+        const int qq = j / NWORDS, wd = j % NWORDS;
+        int c, f;
+        intersect_word(S.bm + qq * NWORDS, wd, NWORDS, P.tx_mintot, &c, &f);
+        if (c) atomicMin(&S.sl->imin[qq], f);
+      }
+      __syncthreads();
+    }
+  }
   // crossing positions (sample units, split int + frac); NaN -> 0 us (dsp_routines.jl:24,41).
   // Seven interpolations, one per lane (lane q < 5: threshold q of y; 5: t0; 6: inverted t0),
   // evaluated once per wave and handed out by readlane.
@@ -1329,8 +1406,8 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   Pos pt0;
   {
     const int q = min(lane, 6);
-    const bool has = S.sl->isum[IS_CNT0 + q] > 0;
     const int p = S.sl->imin[q];
+    const bool has = (q < 5) ? p != 0x7fffffff : S.sl->isum[IS_CNT0 + q] > 0;
     const float frac = (q == 0) ? 0.1f : (q == 1) ? 0.5f : (q == 2) ? 0.8f : (q == 3) ? 0.9f : 0.99f;
     const float thr = (q < 5) ? e_max * frac : P.t0_thr;   // same products as thr_tx[]
     Pos pp; pp.ip = 0; pp.fp = -P.t_first / P.dt;            // sample position of t = 0

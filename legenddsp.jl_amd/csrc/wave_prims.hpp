@@ -105,6 +105,17 @@ __device__ __forceinline__ float wave_min_all(float v) {
   return readlane_f(v, 63);
 }
 
+// unsigned minimum over the wave, result in every lane
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  LDSP_DPP2(4, "v_min_u32_dpp", "row_shr:1 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_min_u32_dpp", "row_shr:2 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_min_u32_dpp", "row_shr:4 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_min_u32_dpp", "row_shr:8 " LDSP_ROWS, v);
+  LDSP_DPP2(1, "v_min_u32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf", v);
+  LDSP_DPP2(1, "v_min_u32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf", v);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Inclusive scan of the recurrence s_l = v_l + a*s_{l-1} over the lanes (one-pole
 // IIR with constant per-lane decay a): s_l = sum_{j<=l} a^(l-j) v_j.
 // The caller supplies exact powers of a (derived in double on the host):

@@ -156,3 +156,36 @@ def test_long_traces_16384(orc):
     ora = orc.dsp_icpc(wf.cpu().numpy(), p, nthreads=8)
     lines, worst = parity.compare(gpu, ora)
     assert worst <= 0.04, "\n".join(lines)
+
+
+def test_threshold_crossings_with_spikes_before_the_pulse(orc, params):
+    """get_threshold (src/dsp_routines.jl:33-42) = Intersect(mintot): the FIRST up-crossing that holds for tx_mintot samples.
+    The kernel confirms the first sample at or above each threshold and falls back to the general bit-mask scan when the
+    confirmation fails: single-sample spikes in the baseline (rejected by mintot = 2 samples), a spike pair (accepted: it IS the
+    first crossing), a trace that starts above the thresholds (initial run: no crossing there), a flat trace (e_max = 0)."""
+    n = 64
+    wf = ldsp.synth.hpge_batch(n, L, device="cuda", seed=77)
+    amp = (wf[:, 6000:6100].mean(dim=1) - wf[:, :2000].mean(dim=1))      # pulse height above baseline
+    for i in range(0, 16):           # one-sample spike above the q-th threshold, well before the rise: must be skipped
+        frac = (0.15, 0.55, 0.85, 0.95, 1.2)[i % 5]
+        wf[i, 500 + 37 * i] += frac * amp[i]
+    for i in range(16, 24):          # two-sample spike: a genuine first crossing of the lower thresholds
+        wf[i, 700 + 11 * i] += 0.6 * amp[i]
+        wf[i, 701 + 11 * i] += 0.6 * amp[i]
+    for i in range(24, 28):          # spike in sample 0 and 1: a run that starts the trace is not a crossing
+        wf[i, 0:2] += 0.7 * amp[i]
+    for i in range(28, 32):          # the trace starts high and comes down: thresholds crossed downwards first
+        wf[i, :300] += 1.5 * amp[i]
+    wf[32] = 1000.0                  # flat: e_max = 0
+    wf[33] = 1000.0 + 0.25 * torch.sin(torch.arange(L, device="cuda") / 50.0)     # tiny ripple: thresholds within the noise
+    gpu = _run(wf, params)
+    ora = orc.dsp_icpc(wf.cpu().numpy(), params, nthreads=16)
+    for c in ("t10", "t50", "t80", "t90", "t99", "t0", "t0_inv", "drift_time", "qdrift", "lq", "e_trap", "e_cusp", "e_zac"):
+        a, b = gpu[c].astype(np.float64), ora[c]
+        tol = 5e-4 if c.startswith("t") else (parity.ATOL[c] + parity.RTOL * np.abs(b))
+        if c == "drift_time":
+            tol = 0.6
+        bad = ~((np.abs(a - b) <= tol) | (np.isnan(a) & np.isnan(b)))
+        assert bad.sum() == 0, (c, np.nonzero(bad)[0], a[bad], b[bad])
+    # the spikes did what they were meant to: traces 0..15 keep their crossing at the pulse, 16..23 moved to the spike pair
+    assert np.all(gpu["t10"][:16] > 40.0) and np.all(gpu["t10"][16:24] < 20.0)
