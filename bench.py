@@ -251,6 +251,7 @@ def bench_icpc(env, args, n, L, workload, wf=None):
     for _ in range(3):
         kernel(out, 0)
         kernel_ms.append(ctx.last_kernel_ms())
+        dom_kernel = ctx.last_kernel_name()     # the name rocprofv3 reports, asked of the library
         if workload == "icpc":
             stage_ms[0].append(ctx.last_stage_ms(0))
             try:   # two launches only when the CUSP/ZAC stage could not be fused
@@ -275,7 +276,6 @@ def bench_icpc(env, args, n, L, workload, wf=None):
         else:
             bytes_per_trace, dom_ms = chain_bytes, kms
         achieved = n * bytes_per_trace / (dom_ms * 1e-3) / 1e9
-        dom_kernel = "icpc_kernel" if workload == "icpc" else "pz_trap_kernel"
         res = {
             "metric": "waveforms/s, full dsp_icpc chain, 8192-sample f32" if workload == "icpc"
             else "waveforms/s, pole-zero + trapezoid sub-chain, 8192-sample f32",
@@ -293,7 +293,7 @@ def bench_icpc(env, args, n, L, workload, wf=None):
             "roofline": roofline(achieved, dom_kernel, dom_ms, bytes_per_trace, measured_traffic(dom_kernel, n, L)),
         }
         if workload == "icpc":
-            res["roofline"]["launches"] = "1 (icpc_kernel, CUSP/ZAC fused)" if fused else "2 (icpc_kernel + icpc_cz_kernel)"
+            res["roofline"]["launches"] = f"1 ({dom_kernel}, CUSP/ZAC fused)" if fused else "2 (icpc_kernel + icpc_cz_kernel)"
             if not fused:
                 res["roofline"]["chain"] = {  # both kernels together against the path's algorithmic bytes
                     "kernels_ms": {"icpc_kernel": k1, "icpc_cz_kernel": k2}, "algorithmic_bytes_per_trace": chain_bytes,
@@ -413,7 +413,7 @@ def bench_sipm(env, args, n, L):
                        "dt_ns": 16.0, "dsp_config": "reference test/test_dsp_sipm.jl:38-68 + sg.wl = 200 ns",
                        "ragged_elements_per_trace": elems / n,
                        "gather": "rccl: scalar table + per trigger group counts -> scan on root -> payload (per-peer sizes)" if world > 1 else "none"},
-            "roofline": roofline(achieved, "k_sipm_s4", kms, bytes_per_trace, measured_traffic("k_sipm_s4", n, L)),
+            "roofline": roofline(achieved, ctx.last_kernel_name(), kms, bytes_per_trace, measured_traffic(ctx.last_kernel_name(), n, L)),
         }
     del wf, bufs
     return res

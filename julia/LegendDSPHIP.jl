@@ -217,6 +217,7 @@ function last_kernel_ms(c::LdspCtx)
     check(ccall((:ldsp_ctx_last_kernel_ms, libldsp), Cint, (Ptr{Cvoid}, Ptr{Cfloat}), c.h, r))
     r[]
 end
+last_kernel_name(c::LdspCtx) = unsafe_string(ccall((:ldsp_ctx_last_kernel_name, libldsp), Cstring, (Ptr{Cvoid},), c.h))
 function last_stage_ms(c::LdspCtx, stage::Integer)
     r = Ref{Cfloat}(0)
     check(ccall((:ldsp_ctx_last_stage_ms, libldsp), Cint, (Ptr{Cvoid}, Cint, Ptr{Cfloat}), c.h, stage, r))

@@ -366,9 +366,21 @@ __global__ void __launch_bounds__(256) k_intersect_maximum(const float* __restri
 }
 
 // MultiIntersect (src/multi_intersect.jl:36-104).  tab: [K ratios | W (m x w) upsampling weights]
-__global__ void __launch_bounds__(64) k_multi_intersect(const float* __restrict__ x, int L, float t_first, float dt,
-                                                        const float* __restrict__ tab, int K, int min_n, int half_n, int m,
-                                                        float* __restrict__ xout, int32_t* __restrict__ status) {
+//
+// The reference walks the trace once with a threshold index that advances at every confirmed crossing and a rewind to
+// the crossing's first sample (:53-72).  For ascending thresholds that walk has a closed form:
+//   pos_0 = Intersect(min_n): the first run of min_n samples >= thr_0 that does not start the trace (:51, the counter
+//           armed at min_n + 1), and
+//   pos_k = the first s >= pos_0 with y[s .. s+min_n-1] >= thr_k              (k >= 1)
+// because the counter restarts at 0 on the rewind (a run may begin AT the restart sample), {y >= thr_k} shrinks with k,
+// and therefore the first window of threshold k from pos_0 is also the first one from pos_{k-1} (pos_{k-1} <= it).  A
+// threshold that is never confirmed ends the walk: it and every later one keep the initial position 1 (:47).
+// So: pos_0 by the block's bit-mask Intersect, then one WAVE per threshold, 64 samples per step by ballot, starting
+// from the wave's previous crossing.  Thresholds that do not ascend (negative maximum, unsorted ratios) or
+// min_n > 32 take the reference's serial walk on one lane.
+__global__ void __launch_bounds__(256) k_multi_intersect(const float* __restrict__ x, int L, float t_first, float dt,
+                                                         const float* __restrict__ tab, int K, int min_n, int half_n, int m,
+                                                         int force_serial, float* __restrict__ xout, int32_t* __restrict__ status) {
   extern __shared__ __align__(16) unsigned char raw[];
   Lds l = carve(raw, L, false);
   const float* xr = x + (size_t)blockIdx.x * L;
@@ -380,11 +392,42 @@ __global__ void __launch_bounds__(64) k_multi_intersect(const float* __restrict_
   float ymax; int imax;
   tb::blk_argmax(bmx, bi, *l.sc, &ymax, &imax);
   __shared__ int s_ipos[LDSP_MAX_MULTI];
-  __shared__ int s_rc;
-  if (tid == 0) {
+  __shared__ int s_rc, s_desc;
+  if (tid == 0) s_desc = 0;
+  for (int k = tid; k < K; k += NT) s_ipos[k] = 1;
+  __syncthreads();
+  for (int k = tid; k + 1 < K; k += NT) if (!(tab[k + 1] * ymax >= tab[k] * ymax)) s_desc = 1;
+  const float th0 = tab[0] * ymax;
+  tb::build_mask(l.s, L, 1.f, th0, l.bm);
+  __syncthreads();
+  const bool serial = force_serial || s_desc || min_n > 32;
+  if (!serial) {
+    int first, count;
+    tb::intersect_scan(l.bm, L, min_n, *l.sc, &first, &count);
+    if (count > 0) {
+      const int wave = tid >> 6, lane = tid & 63, nw = NT >> 6;
+      if (tid == 0) s_ipos[0] = first;
+      int base = first;                      // a later threshold's window is never left of an earlier one's
+      const int stride = 64 - (min_n - 1);   // every window of min_n samples lies inside one step
+      for (int k = 1 + wave; k < K; k += nw) {
+        const float th = tab[k] * ymax;
+        int pos = -1;
+        while (base < L) {
+          const int i = base + lane;
+          const float v = i < L ? l.s[i] : -INFINITY;
+          unsigned long long r = __ballot(v >= th);
+          for (int j = 1; j < min_n; ++j) r &= r >> 1;     // bit s: samples s .. s+min_n-1 of this step all high
+          if (r) { pos = base + (int)__builtin_ctzll(r); break; }
+          base += stride;
+        }
+        if (pos < 0) break;                  // not confirmed: neither is any later threshold
+        base = pos;
+        if (lane == 0) s_ipos[k] = pos;
+      }
+    }
+  } else if (tid == 0) {
     // the reference's scan with threshold index advance and rewind (:53-72)
     const float* ratios = tab;
-    for (int k = 0; k < K; ++k) s_ipos[k] = 1;
     int cand = 1, ic = 0, i = 0;
     int cnt = (l.s[0] >= ratios[0] * ymax) ? min_n + 1 : 0;
     while (i < L && ic < K) {
@@ -398,8 +441,9 @@ __global__ void __launch_bounds__(64) k_multi_intersect(const float* __restrict_
       i = found ? pos : i + 1;
       if (found) { ++ic; cnt = 0; }
     }
-    s_rc = (s_ipos[0] - half_n >= 0 && s_ipos[K - 1] + half_n - 1 <= L - 1) ? 0 : LDSP_ERR_WINDOW;  // :75-78
   }
+  __syncthreads();
+  if (tid == 0) s_rc = (s_ipos[0] - half_n >= 0 && s_ipos[K - 1] + half_n - 1 <= L - 1) ? 0 : LDSP_ERR_WINDOW;  // :75-78
   __syncthreads();
   const int w = 2 * half_n;
   const float* W = tab + K;
@@ -703,8 +747,8 @@ int ldsp_multi_intersect(ldsp_ctx* c, const float* x, int64_t n, int32_t L, doub
   }
   if ((rc = upload_coef(c, tab))) return rc;
   if ((rc = set_lds(k_multi_intersect, b))) return rc;
-  hipLaunchKernelGGL(k_multi_intersect, dim3((unsigned)n), dim3(64), b, c->stream, x, L, (float)t_first, (float)dt,
-                     (const float*)c->d_coef, K, min_n, half_n, m, xout, status);
+  hipLaunchKernelGGL(k_multi_intersect, dim3((unsigned)n), dim3(256), b, c->stream, x, L, (float)t_first, (float)dt,
+                     (const float*)c->d_coef, K, min_n, half_n, m, c->multi_serial ? 1 : 0, xout, status);
   LAUNCH_CHECK();
   return LDSP_OK;
 }

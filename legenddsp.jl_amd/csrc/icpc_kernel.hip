@@ -24,6 +24,7 @@
 #include <type_traits>
 #include "icpc_dev.hpp"
 #include "ldsp_device.hpp"
+#include "qdrift.hpp"
 
 // LDSP_DEV_512: development builds instantiate the 512-thread kernels only (one fifth of the compile time); the dev
 // library answers LDSP_ERR for other trace lengths.  LDSP_STAMPS: diagnostic build, every wave of the first blocks writes
@@ -1446,26 +1447,29 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   {
     float* eslot = S.misc + 4;
     auto I = [&](int i) { return S.B1[i + 1]; };  // integrator output I[i] = T[i+1]  (dsp_routines.jl:53)
-    for (int e = wave; e < 7; e += NW) {
+    // qdrift / lq (get_qdrift, dsp_routines.jl:51-64; lq from t80 with lq_int_length, dsp_icpc.jl:144): one wave each, the
+    // integrator output taken relative to the first window point (qdrift.hpp) — exact where a difference of two float32
+    // prefix sums of 1e8 would carry +-40
+    for (int e = wave; e < 3; e += NW) {
       float v;
       if (e == 0) {
         Pos p = pos_add(ptx[1], P.trap_pickoff);
         p.ip -= (P.opt.flen - 1);
         v = estimate(P.sig_est, S.estB, p, L - P.opt.flen + 1, [&](int i) { return trap_at(S.B1, i, P.opt); });
-      } else if (e <= 3) {  // get_qdrift(wvfs, t0, qdrift_int_length)   dsp_routines.jl:51-64
-        const float d = (e == 1) ? 0.f : (e == 2 ? P.qdrift_d1 : P.qdrift_d2);
-        v = estimate(P.int_est, S.estB + EST_TBL, pos_add(pt0, d), L, I);
-      } else {              // lq: the same from t80 with lq_int_length      dsp_icpc.jl:144
-        const float d = (e == 4) ? 0.f : (e == 5 ? P.lq_d1 : P.lq_d2);
-        v = estimate(P.int_est, S.estB + EST_TBL, pos_add(ptx[2], d), L, I);
+      } else {
+        const Pos base = (e == 1) ? pt0 : ptx[2];
+        const Pos p1 = pos_add(base, e == 1 ? P.qdrift_d1 : P.lq_d1), p2 = pos_add(base, e == 1 ? P.qdrift_d2 : P.lq_d2);
+        const int ips[3] = {base.ip, p1.ip, p2.ip};
+        const float fps[3] = {base.fp, p1.fp, p2.fp};
+        v = qdrift_wave(P.int_est, S.estB + EST_TBL, S.B0, L, ips, fps);
       }
       if (lane == 0) eslot[e] = v;
     }
     __syncthreads();
     if (tid == 0) {
       S.outv[C_e_trap] = eslot[0];
-      S.outv[C_qdrift] = (eslot[3] - eslot[2]) - (eslot[2] - eslot[1]);
-      S.outv[C_lq] = (eslot[6] - eslot[5]) - (eslot[5] - eslot[4]);
+      S.outv[C_qdrift] = eslot[1];
+      S.outv[C_lq] = eslot[2];
     }
   }
   if (P.dbg_stop == 6) return;

@@ -19,6 +19,10 @@ namespace ldsp {
 hipError_t launch_icpc(const float* wf, int64_t n, int NT, int R, bool full, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
                        const float* ext_bl, float ext_bl_scale, bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid,
                        int* stages);
+hipError_t launch_icpc_lean(const float* wf, int64_t n, int NT, int sg_slots, const IcpcDev* dP, const IcpcOutDev& out, const float* ext_bl,
+                            float ext_bl_scale, int Lf, hipStream_t st);
+size_t icpc_lean_smem_bytes(int NT, int Lf);
+hipError_t launch_pz_trap_lean(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 size_t icpc_smem_bytes(int NT);
 hipError_t launch_trap_grid(const float* wf, int64_t n, int NT, bool full, const TrapGridDev* dP, float* out, hipStream_t st);
@@ -129,8 +133,10 @@ int ldsp_ctx_set_option(ldsp_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "two_kernel")) { c->two_kernel = value != 0; return LDSP_OK; }
   if (!strcmp(key, "sipm_generic")) { c->sipm_generic = value != 0; return LDSP_OK; }
   if (!strcmp(key, "dbg_stop")) { c->dbg_stop = (int)value; c->icpc_valid = false; return LDSP_OK; }
+  if (!strcmp(key, "icpc_generic")) { c->icpc_generic = value != 0; return LDSP_OK; }
   if (!strcmp(key, "icpc_r2")) { c->icpc_r2 = value != 0; c->icpc_valid = false; return LDSP_OK; }
   if (!strcmp(key, "dbg_stamps")) { c->dbg_stamps = reinterpret_cast<long long*>((uintptr_t)value); c->icpc_valid = false; return LDSP_OK; }
+  if (!strcmp(key, "multi_serial")) { c->multi_serial = value != 0; return LDSP_OK; }
   if (!strcmp(key, "fir_grid_per_point")) { c->fir_grid_per_point = value != 0; return LDSP_OK; }
   return fail(LDSP_ERR_INVALID_ARG, "unknown option '%s'", key);
 }
@@ -150,6 +156,8 @@ int ldsp_ctx_last_kernel_ms(ldsp_ctx* c, float* ms) {
   *ms = t / (float)c->n_launches;
   return LDSP_OK;
 }
+
+const char* ldsp_ctx_last_kernel_name(ldsp_ctx* c) { return c ? c->last_kernel : ""; }
 
 int ldsp_ctx_last_stage_ms(ldsp_ctx* c, int stage, float* ms) {
   if (!c || !ms) return fail(LDSP_ERR_INVALID_ARG, "ctx/ms is NULL");
@@ -334,12 +342,38 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, int r2, Ic
   d.cz_shared = p.cusp.sigma == p.zac.sigma && p.cusp.flat == p.zac.flat && p.cusp.length == p.zac.length &&
                 p.cusp.tau == p.zac.tau && p.cusp.beta == p.zac.beta;
   d.cusp_mode = (cusp_direct || !cz_ok) ? 0 : 1;  // unexpected kernel structure -> direct-form comparator
+  {
+    const int wlo = std::min(std::min(d.cur_from[1], d.cur_from[2]), d.cur_from[3]), whi = std::max(std::max(d.cur_until[1], d.cur_until[2]), d.cur_until[3]);
+    const int win[5][2] = {{d.bl.from, d.bl.until}, {d.tail.from, d.tail.until}, {d.sgbl.from, d.sgbl.until}, {d.cur_from[0], d.cur_until[0]}, {wlo, whi}};
+    for (int w = 0; w < 5; ++w)
+      for (int v = 0; v < 16; ++v) {
+        uint32_t m = 0;
+        for (int r = 0; r < 4; ++r) {
+          const int a = 4 * (64 * v + d.NT * r), b = a + 255;
+          if (b < win[w][0] || a > win[w][1]) m |= 1u << r;
+          else if (a >= win[w][0] && b <= win[w][1]) m |= 16u << r;
+        }
+        d.rowcls[w][v] = m;
+      }
+  }
   std::vector<double> h;
   hm::cuspzac_taps(p.cusp, false, h);
   hc.assign(h.begin(), h.end());
   hm::cuspzac_taps(p.zac, true, h);
   hz.assign(h.begin(), h.end());
   return LDSP_OK;
+}
+
+// the lean kernels (icpc_lean.hip) cover the standard geometry: the trace fills the tile, CUSP and ZAC share their geometry
+// (closed form), the inverted t0 uses the same trapezoid, tx_mintot = 2 samples, Savitzky-Golay windows of at most 13 taps,
+// two traces per CU.  ldsp_icpc_run and ldsp_icpc_pz_trap_run decide alike, so that config 2's columns stay bit-identical
+// to the fused chain's.
+static bool icpc_lean_applies(const ldsp_ctx* c) {
+  const IcpcDev& H = c->icpc_host;
+  const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
+  return !c->icpc_generic && !c->two_kernel && (c->dbg_stop == 0 || c->dbg_stop >= 100) && H.R == 4 && H.L == 16 * H.NT && H.cusp_mode == 1 &&
+         H.cz_shared && H.t0inv_same && H.tx_mintot == 2 && sg_max <= 13 &&
+         icpc_lean_smem_bytes(H.NT, H.cusp.Lf) <= 80640;   // two traces per CU (160 KiB LDS, 1280-byte granules)
 }
 
 static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p) {
@@ -391,11 +425,22 @@ int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_
   }
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   int stages = 1;
+  // the lean kernel (icpc_lean.hip) covers the standard geometry; everything else — and option "icpc_generic" — runs icpc_kernel
+  const IcpcDev& H = c->icpc_host;
+  const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
+  const bool lean_ok = icpc_lean_applies(c) && !main_only;
+  if (lean_ok) {
+    HIP_TRY(launch_icpc_lean(wf, n, H.NT, sg_max, c->d_icpc, od, ext_bl, ext_bl_scale, H.cusp.Lf, c->stream));
+    c->last_kernel = "lean::icpc_lean_kernel";
+    if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
+    return LDSP_OK;
+  }
   HIP_TRY(launch_icpc(wf, n, c->icpc_host.NT, c->icpc_host.R, c->icpc_host.L == 4 * c->icpc_host.R * c->icpc_host.NT, c->d_icpc, c->d_aux, od, ext_bl, ext_bl_scale,
                       c->icpc_host.cusp_mode == 0, c->icpc_host.cz_shared != 0, !c->two_kernel && !main_only,
                       main_only || (c->dbg_stop > 0 && c->dbg_stop < 10),
                       ((std::max(c->icpc_host.cusp.Lf, c->icpc_host.zac.Lf) + 2 + 7) & ~3), c->stream,
                       c->timing ? c->evm : nullptr, &stages));
+  c->last_kernel = "icpc_kernel";
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = stages; }
   return LDSP_OK;
 }
@@ -410,7 +455,13 @@ int ldsp_icpc_pz_trap_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_ic
   if (rc) return rc;
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   const int nt_pz = c->icpc_host.R == 2 ? 512 : c->icpc_host.NT;   // pz_trap_kernel keeps 16 samples per thread
-  HIP_TRY(launch_pz_trap(wf, n, nt_pz, c->icpc_host.L == 16 * nt_pz, c->d_icpc, blmean, e_10410, c->stream));
+  if (icpc_lean_applies(c)) {
+    HIP_TRY(launch_pz_trap_lean(wf, n, c->icpc_host.NT, c->d_icpc, blmean, e_10410, c->stream));
+    c->last_kernel = "lean::pz_trap_lean_kernel";
+  } else {
+    HIP_TRY(launch_pz_trap(wf, n, nt_pz, c->icpc_host.L == 16 * nt_pz, c->d_icpc, blmean, e_10410, c->stream));
+    c->last_kernel = "pz_trap_kernel";
+  }
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
   return LDSP_OK;
 }
@@ -450,6 +501,7 @@ int ldsp_trap_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapg
   HIP_TRY(hipStreamSynchronize(c->stream));   // the staging block is reused by the next call
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   HIP_TRY(launch_trap_grid(wf, n, d.NT, L == 16 * d.NT, reinterpret_cast<const TrapGridDev*>(c->d_grid), out, c->stream));
+  c->last_kernel = "trap_grid_kernel";
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
   return LDSP_OK;
 }
@@ -500,6 +552,7 @@ int ldsp_fir_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgr
   HIP_TRY(hipStreamSynchronize(c->stream));   // the staging vectors die at return
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   HIP_TRY(launch_fir_grid(wf, n, d.NT, L == 16 * d.NT, reinterpret_cast<const FirGridDev*>(c->d_grid), out, c->stream));
+  c->last_kernel = "fir_grid_kernel";
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
   return LDSP_OK;
 }
@@ -545,6 +598,7 @@ int ldsp_sg_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgri
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   HIP_TRY(launch_sg_grid(wf, n, d.NT, L == 16 * d.NT, reinterpret_cast<const SgGridDev*>(c->d_sg_grid), amax, energy, t50_us, blmean, blslope, c->stream));
+  c->last_kernel = "sg_grid_kernel";
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
   return LDSP_OK;
 }

@@ -37,13 +37,16 @@ struct ldsp_ctx {
   int sipm_generic = 0; // option "sipm_generic": always the generic two-array dsp_sipm kernel
   int two_kernel = 0;   // option "two_kernel": never fuse the CUSP/ZAC stage into icpc_kernel
   int dbg_stop = 0;
+  int icpc_generic = 0;  // option "icpc_generic": always icpc_kernel, never the lean kernel (comparator)
   int icpc_r2 = 0;      // option "icpc_r2": 4097..8192-sample traces on 1024 threads x 8 samples (8 waves per SIMD) instead of 512 x 16
   long long* dbg_stamps = nullptr;   // option "dbg_stamps": device buffer of a diagnostic (LDSP_STAMPS) build
+  int multi_serial = 0;          // option "multi_serial": MultiIntersect by the reference's one-lane walk (comparator of the wave-parallel search)
   int fir_grid_per_point = 0;    // option "fir_grid_per_point": ldsp_fir_grid_run evaluates every grid point's filter outputs (comparator)
   // timing
   int timing = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;  // evm: boundary between the two dsp_icpc kernels
   int n_launches = 0, n_stages = 1;
+  const char* last_kernel = "";   // dominant kernel of the last ldsp_*_run call (static string)
 };
 
 // common argument checks of the per-trace entry points

@@ -170,6 +170,9 @@ __device__ __forceinline__ bool bits_all_set(const uint32_t* bm, int s, int len,
 __device__ __forceinline__ void intersect_word(const uint32_t* bm, int w, int nwords, int min_n, int* cnt, int* first) {
   uint32_t h = bm[w];
   if (h == 0u) { *cnt = 0; *first = 0x7fffffff; return; }  // no run can start in an empty word (most words of a sparse mask)
+  // a run of min_n >= 64 samples that starts in this word covers the whole next word: a flickering mask (threshold inside the
+  // noise: the t0 trapezoid on a baseline) has several short runs per word and none of them needs a closer look
+  if (min_n >= 64 && (w + 1 >= nwords || bm[w + 1] != 0xffffffffu)) { *cnt = 0; *first = 0x7fffffff; return; }
   uint32_t prev = (w == 0) ? 1u : (bm[w - 1] >> 31);  // sample -1 counts as "high": initial run excluded
   uint32_t starts = h & ~((h << 1) | prev);
   if (min_n >= 2) {  // cheap prune: the sample after a run start must be high too

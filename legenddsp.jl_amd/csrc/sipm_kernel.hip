@@ -259,6 +259,7 @@ extern "C" int ldsp_sipm_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp
     else if (L <= 8192) e = LDSP_S4(256);
     else if (L <= 16384) e = LDSP_S4(512);
     else launched = false;
+    if (launched) c->last_kernel = "sipm::k_sipm_s4";
 #undef LDSP_S4
   }
   if (!launched) {
@@ -268,6 +269,7 @@ extern "C" int ldsp_sipm_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sipm::k_sipm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     const int nt = L <= 4096 ? 256 : (L <= 8192 ? 512 : 1024);
     hipLaunchKernelGGL(sipm::k_sipm, dim3((unsigned)n), dim3(nt), bytes, c->stream, wf, d, od);
+    c->last_kernel = "sipm::k_sipm";
     e = hipGetLastError();
   }
   if (e != hipSuccess) return ldsp_fail(LDSP_ERR_HIP, "launch: %s", hipGetErrorString(e));

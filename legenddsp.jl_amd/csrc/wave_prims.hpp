@@ -153,3 +153,77 @@ __device__ __forceinline__ float wave_shl1(float v) {
 }
 
 }  // namespace ldsp
+
+// ---- interleaved DPP chains ------------------------------------------------------------------------------------
+// A wave issues one instruction every ~8-9 cycles whatever its kind (tools/micro/valu_rate3.hip), so the `s_nop` in front of
+// every step of the scans above costs as much as the step itself.  LDSP_DPP_GROUPn(op0, v0, op1, v1, ...) runs n INDEPENDENT
+// chains (op = "v_add_f32_dpp", "v_max_f32_dpp", "v_min_f32_dpp", "v_min_u32_dpp") interleaved: one asm statement per step,
+// holding that step of every chain, with ALL values as operands — the compiler then cannot place a write of one of them
+// between the leading s_nop and its first DPP read (with separate statements it did: a scan that started from a stale
+// register).  With three or more chains the two wait states a DPP read needs after a VALU write of the same VGPR are filled by
+// the other chains; one or two chains keep an s_nop in every step.  After the last step lane 63 holds the wave total /
+// maximum / minimum and lane l the inclusive scan (sums).
+#define LDSP_DPP_GROUP1(O0, v0) do { \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0)); \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0)); \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0)); \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0)); \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0)); \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0)); \
+} while (0)
+#define LDSP_DPP_GROUP2(O0, v0, O1, v1) do { \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1)); \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1)); \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1)); \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1)); \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1)); \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1)); \
+} while (0)
+#define LDSP_DPP_GROUP3(O0, v0, O1, v1, O2, v2) do { \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2)); \
+  asm volatile(O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2)); \
+  asm volatile(O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2)); \
+} while (0)
+#define LDSP_DPP_GROUP4(O0, v0, O1, v1, O2, v2, O3, v3) do { \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)); \
+  asm volatile(O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)); \
+  asm volatile(O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)); \
+} while (0)
+#define LDSP_DPP_GROUP5(O0, v0, O1, v1, O2, v2, O3, v3, O4, v4) do { \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4)); \
+  asm volatile(O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4)); \
+  asm volatile(O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4)); \
+} while (0)
+#define LDSP_DPP_GROUP6(O0, v0, O1, v1, O2, v2, O3, v3, O4, v4, O5, v5) do { \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5)); \
+  asm volatile(O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5)); \
+  asm volatile(O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5)); \
+} while (0)
+#define LDSP_DPP_GROUP7(O0, v0, O1, v1, O2, v2, O3, v3, O4, v4, O5, v5, O6, v6) do { \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6)); \
+  asm volatile(O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6)); \
+  asm volatile(O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6)); \
+} while (0)
+#define LDSP_DPP_GROUP8(O0, v0, O1, v1, O2, v2, O3, v3, O4, v4, O5, v5, O6, v6, O7, v7) do { \
+  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)); \
+  asm volatile(O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)); \
+  asm volatile(O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)); \
+  asm volatile(O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)); \
+} while (0)

@@ -128,6 +128,97 @@ def batch():
     return ldsp.ArrayOfRDWaveforms((wf - blm).contiguous(), 0.0, DT)
 
 
+def _multi_oracle(orc, x, ratios, min_n, half_n, degree, rate, dt=DT):
+    """Per trace: the oracle's K crossing times, or None where the reference's boundary @assert fires."""
+    res = []
+    for row in x:
+        try:
+            res.append(orc.multi_intersect(row, ratios, min_n, half_n, degree, rate, t_first=0.0, dt=dt))
+        except orc.OracleError:
+            res.append(None)
+    return res
+
+
+@pytest.mark.parametrize("mintot_samples,half_n,degree,rate", [(2, 1, 1, 1), (3, 1, 1, 1), (4, 2, 1, 4), (5, 2, 2, 4), (6, 3, 2, 2), (40, 1, 1, 1)])
+def test_multi_intersect_matches_oracle_on_hpge_traces(orc, batch, mintot_samples, half_n, degree, rate):
+    """MultiIntersect with the reference's default 90 thresholds (src/multi_intersect.jl:12): the wave-parallel search
+    (one wave per threshold, closed form of the reference's advance-and-rewind walk) against the oracle's serial walk, and
+    against the kernel's own one-lane walk (option multi_serial) bit for bit.  mintot 40 samples takes the serial path."""
+    ratios = tuple(np.arange(0.01, 0.905, 0.01))
+    f = ldsp.MultiIntersect(threshold_ratios=ratios, mintot=mintot_samples * DT, n=half_n, d=degree, sampling_rate=rate)
+    got = host(f(batch)).astype(np.float64)
+    x = host(batch.signal).astype(np.float64)
+    ora = _multi_oracle(orc, x, ratios, mintot_samples, half_n, degree, rate)
+    assert all(o is not None for o in ora)
+    ora = np.stack(ora)
+    bad = ~(np.abs(got - ora) <= 0.02 * DT)            # 0.02 sample: float32 interpolation of a noisy edge
+    assert bad.sum() == 0, (np.argwhere(bad)[:10], got[bad][:10], ora[bad][:10])
+    ctx = ldsp.default_context(batch.signal.device.index)
+    ctx.set_option("multi_serial", 1)
+    try:
+        serial = host(f(batch))
+    finally:
+        ctx.set_option("multi_serial", 0)
+    assert np.array_equal(serial, host(f(batch)))
+
+
+def test_multi_intersect_hard_traces_and_window_status(orc):
+    """Traces on which the walk does not simply climb the edge: spikes before the pulse (a confirmed early crossing of
+    the low thresholds only, later thresholds cross at the edge), an initial run above the first thresholds, thresholds that
+    are never confirmed (positions stay at sample 1), a negative trace (descending thresholds: serial path), a pulse
+    at the very end / start (the reference's boundary @assert, src/multi_intersect.jl:75-78 -> status and WindowError)."""
+    L, K = 4096, 90
+    ratios = tuple(np.arange(0.01, 0.905, 0.01))
+    rng = np.random.default_rng(12)
+    t = np.arange(L)
+    edge = 1000.0 / (1.0 + np.exp(-(t - 2000) / 40.0))
+    rows = []
+    for i in range(24):
+        y = edge + rng.normal(0, 2.0, L)
+        if i % 6 == 1:
+            y[300:300 + 2 + i % 5] += 250.0           # short plateau before the pulse: low thresholds confirm there
+        if i % 6 == 2:
+            y[:50] += 400.0                           # the trace starts above the first thresholds
+        if i % 6 == 3:
+            y[2500:] = 0.0; y[2100] += 5000.0         # maximum is one spike: high thresholds never confirmed for mintot >= 2
+        if i % 6 == 4:
+            y = -y - 50.0                             # negative maximum: thresholds descend
+        if i % 6 == 5:
+            y = np.roll(y, -1990 + 3 * (i // 6))      # the edge sits at the start of the trace
+        rows.append(y)
+    x = np.asarray(rows, dtype=np.float32)
+    w = wv(x)
+    ctx = ldsp.default_context(w.signal.device.index)
+    ctx.bind_stream()
+    import ctypes as C
+    from legenddsp_jl_amd import _lib
+    for min_n, half_n, degree, rate in [(1, 1, 1, 1), (2, 1, 1, 1), (4, 2, 1, 2), (6, 2, 2, 4)]:
+        ora = _multi_oracle(orc, x.astype(np.float64), ratios, min_n, half_n, degree, rate)
+        out = torch.empty((len(rows), K), dtype=torch.float32, device="cuda")
+        status = torch.empty(len(rows), dtype=torch.int32, device="cuda")
+        r = np.ascontiguousarray(ratios, dtype=np.float64)
+        for serial in (0, 1):
+            ctx.set_option("multi_serial", serial)
+            try:
+                _lib.check(_lib.lib().ldsp_multi_intersect(ctx.handle, C.c_void_p(w.signal.data_ptr()), len(rows), L, 0.0, DT,
+                                                           r.ctypes.data_as(C.c_void_p), K, min_n, half_n, degree, rate,
+                                                           C.c_void_p(out.data_ptr()), C.c_void_p(status.data_ptr())))
+            finally:
+                ctx.set_option("multi_serial", 0)
+            st, got = host(status), host(out).astype(np.float64)
+            nerr = 0
+            for i, o in enumerate(ora):
+                assert (st[i] != 0) == (o is None), (min_n, half_n, serial, i, st[i])
+                if o is None:
+                    nerr += 1
+                    continue
+                ok = (np.abs(got[i] - o) <= 0.02 * DT) | (np.isnan(got[i]) & np.isnan(o))
+                assert ok.all(), (min_n, half_n, serial, i, np.nonzero(~ok)[0][:8], got[i][~ok][:8], o[~ok][:8])
+        assert nerr > 0                                # the batch does hold window-error traces
+        with pytest.raises(ldsp.WindowError):
+            ldsp.MultiIntersect(threshold_ratios=ratios, mintot=min_n * DT, n=half_n, d=degree, sampling_rate=rate)(w)
+
+
 def _each(batch, fn):
     x = host(batch.signal).astype(np.float64)
     return [fn(x[i]) for i in range(x.shape[0])]

@@ -1,0 +1,44 @@
+"""Fixed-seed cases of the randomised parity sweeps (tools/fuzz_icpc.py / tools/fuzz_sipm.py run the same generator
+open-ended): dsp_icpc and dsp_sipm through the C ABI against the oracle with randomised filter parameters, tau, window
+placement, trace lengths that do and do not fill a tile, noise levels, pile-up, flat-topped and rail-saturated traces,
+discharges and ADC quantisation.  tests/fuzz_cases.py holds the generator (seed 1)."""
+import numpy as np
+import pytest
+import torch
+
+import legenddsp_jl_amd as ldsp
+import fuzz_cases
+import parity
+
+pytestmark = pytest.mark.gpu
+SEED = 1
+
+
+# L = 6000 / 7300 (ragged tiles, generic kernel), 8192 and 16384 (full tiles: the lean kernel when CUSP and ZAC share their
+# geometry — cases 5 and 10 — the generic one otherwise)
+@pytest.mark.parametrize("it", [0, 2, 4, 5, 8, 9, 10, 13])
+def test_icpc_randomised_configuration(orc, it):
+    n = 256
+    L, dt, cfg, tau, pf, noise, descr = fuzz_cases.icpc_case(SEED, it)
+    p = ldsp.lower_icpc(cfg, tau, pf, L, 0.0, dt)
+    wf = fuzz_cases.icpc_traces(n, L, it, noise)
+    tab = ldsp.icpc_run(wf, p)
+    torch.cuda.synchronize()
+    gpu = {k: v.cpu().numpy() for k, v in ldsp.table_columns(tab).items()}
+    ora = orc.dsp_icpc(wf.cpu().numpy(), p, nthreads=16, strict=False)
+    lines, worst = parity.compare(gpu, ora)
+    bad = [l for l in lines if not l.rstrip().endswith(f"bad=0/{n}")]
+    assert worst <= parity.FLIP_FRAC, descr + "\n" + "\n".join(bad)
+
+
+@pytest.mark.parametrize("it", range(6))
+def test_sipm_randomised_configuration(orc, it):
+    n = 192
+    L, cfg, pf, noise, mean_pulses, descr = fuzz_cases.sipm_case(SEED, it)
+    p = ldsp.lower_sipm(cfg, pf, L, 0.0, 16.0)
+    wf = fuzz_cases.sipm_traces(n, L, it, noise, mean_pulses)
+    sc, trig = ldsp.sipm_run(wf, p)
+    torch.cuda.synchronize()
+    ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=16)
+    msgs = fuzz_cases.sipm_compare(sc, trig, ora, n)
+    assert not msgs, descr + ": " + "; ".join(msgs)

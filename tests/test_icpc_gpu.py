@@ -16,12 +16,18 @@ def params():
     return ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, L, 0.0, 16.0)
 
 
-def _run(wf, params, direct=0):
+def _run(wf, params, direct=0, generic=0):
+    """direct: CUSP/ZAC as direct-form FIR (comparator of the closed form); generic: icpc_kernel instead of the lean kernel
+    (icpc_lean.hip) where both apply"""
     ctx = ldsp.default_context()
     ctx.set_option("cusp_direct", direct)
-    tab = ldsp.icpc_run(wf, params, ctx)
-    torch.cuda.synchronize()
-    ctx.set_option("cusp_direct", 0)
+    ctx.set_option("icpc_generic", generic)
+    try:
+        tab = ldsp.icpc_run(wf, params, ctx)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_option("cusp_direct", 0)
+        ctx.set_option("icpc_generic", 0)
     return {k: v.cpu().numpy() for k, v in ldsp.table_columns(tab).items()}
 
 
@@ -32,11 +38,13 @@ def test_native_library_loaded():
         assert "libldsp_hip.so" in f.read()
 
 
-@pytest.mark.parametrize("direct", [0, 1])
-def test_icpc_matches_oracle_seeded_batch(orc, params, direct):
+@pytest.mark.parametrize("direct,generic", [(0, 0), (0, 1), (1, 0)])
+def test_icpc_matches_oracle_seeded_batch(orc, params, direct, generic):
+    """(0, 0): the lean kernel (the production path at this geometry); (0, 1): icpc_kernel on the same batch; (1, 0): direct-form
+    CUSP/ZAC (two launches of the generic kernels)"""
     n = 512 if direct == 0 else 128
     wf = ldsp.synth.hpge_batch(n, L, device="cuda")
-    gpu = _run(wf, params, direct)
+    gpu = _run(wf, params, direct, generic)
     ora = orc.dsp_icpc(wf.cpu().numpy(), params, nthreads=16)
     lines, worst = parity.compare(gpu, ora)
     print("\n".join(lines))
@@ -178,14 +186,19 @@ def test_threshold_crossings_with_spikes_before_the_pulse(orc, params):
         wf[i, :300] += 1.5 * amp[i]
     wf[32] = 1000.0                  # flat: e_max = 0
     wf[33] = 1000.0 + 0.25 * torch.sin(torch.arange(L, device="cuda") / 50.0)     # tiny ripple: thresholds within the noise
-    gpu = _run(wf, params)
     ora = orc.dsp_icpc(wf.cpu().numpy(), params, nthreads=16)
-    for c in ("t10", "t50", "t80", "t90", "t99", "t0", "t0_inv", "drift_time", "qdrift", "lq", "e_trap", "e_cusp", "e_zac"):
-        a, b = gpu[c].astype(np.float64), ora[c]
-        tol = 5e-4 if c.startswith("t") else (parity.ATOL[c] + parity.RTOL * np.abs(b))
-        if c == "drift_time":
-            tol = 0.6
-        bad = ~((np.abs(a - b) <= tol) | (np.isnan(a) & np.isnan(b)))
-        assert bad.sum() == 0, (c, np.nonzero(bad)[0], a[bad], b[bad])
-    # the spikes did what they were meant to: traces 0..15 keep their crossing at the pulse, 16..23 moved to the spike pair
-    assert np.all(gpu["t10"][:16] > 40.0) and np.all(gpu["t10"][16:24] < 20.0)
+    smooth = np.ones(n, dtype=bool)
+    smooth[24:34] = False    # steps of the full pulse height next to the windows: qdrift / lq there move by hundreds per 0.01 sample of t0
+    for generic in (0, 1):   # the lean kernel and icpc_kernel share the confirmation + fall-back scheme
+        gpu = _run(wf, params, generic=generic)
+        for c in ("t10", "t50", "t80", "t90", "t99", "t0", "t0_inv", "drift_time", "qdrift", "lq", "e_trap", "e_cusp", "e_zac"):
+            a, b = gpu[c].astype(np.float64), ora[c]
+            tol = 5e-4 if c.startswith("t") else (parity.ATOL[c] + parity.RTOL * np.abs(b))
+            if c == "drift_time":
+                tol = 0.6
+            bad = ~((np.abs(a - b) <= tol) | (np.isnan(a) & np.isnan(b)))
+            if c in ("qdrift", "lq"):
+                bad &= smooth
+            assert bad.sum() == 0, (generic, c, np.nonzero(bad)[0], a[bad], b[bad])
+        # the spikes did what they were meant to: traces 0..15 keep their crossing at the pulse, 16..23 moved to the spike pair
+        assert np.all(gpu["t10"][:16] > 40.0) and np.all(gpu["t10"][16:24] < 20.0)

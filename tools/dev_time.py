@@ -30,14 +30,26 @@ for rnd in range(6):
 for on in ((False, True) if opts else (False,)):
     t = np.array(ts[on])
     print(f"{'variant ' + str(opts) if on else 'default':40s} min {t.min():.3f} ms  median {np.median(t):.3f} ms  -> {n / t.min() * 1e-3:.2f} M waveforms/s")
-# parity of the last configuration run
+# parity of both configurations
 from oracle import oracle as orc
 import parity
 m = min(n, 512)
-g = {k: v[:m].cpu().numpy() for k, v in ldsp.table_columns(out).items()}
 o = orc.dsp_icpc(wf[:m].cpu().numpy(), p, nthreads=16)
-lines, worst = parity.compare(g, o)
-bad = [l for l in lines if not l.rstrip().endswith(" 0")]
-print(f"parity vs oracle on {m} traces: worst bad fraction {worst:.4f}")
-if worst > 0:
-    print("\n".join(lines))
+tabs = {}
+for on in ((False, True) if opts else (False,)):
+    setopts(on)
+    ldsp.icpc_run(wf, p, ctx, out=out)
+    torch.cuda.synchronize()
+    tabs[on] = out[:4096].clone()
+    g = {k: v[:m].cpu().numpy() for k, v in ldsp.table_columns(out).items()}
+    lines, worst = parity.compare(g, o)
+    print(f"{'variant' if on else 'default'}: parity vs oracle on {m} traces: worst bad fraction {worst:.4f}")
+    if worst > 0:
+        print("\n".join(l for l in lines if not l.rstrip().endswith("bad=0/%d" % m)))
+    if os.environ.get("DEV_TIME_VERBOSE"):
+        print("\n".join(lines))
+if opts:
+    a, b = tabs[False].cpu().numpy(), tabs[True].cpu().numpy()
+    cols = ldsp._abi.ICPC_COLS
+    diff = [(c, float(np.nanmax(np.abs(a[:, i].astype(np.float64) - b[:, i]))), int((a[:, i].view(np.int32) != b[:, i].view(np.int32)).sum())) for i, c in enumerate(cols)]
+    print("default vs variant, per column (max |diff|, rows whose bits differ): " + ", ".join(f"{c} {d:.3g}/{k}" for c, d, k in diff if k))
