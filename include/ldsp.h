@@ -383,7 +383,9 @@ int ldsp_intersect_maximum(ldsp_ctx*, const float* x, int64_t n, int32_t L, doub
                            const float* thr, int32_t min_n, int32_t max_n, const ldsp_trig_out* out);
 /* MultiIntersect(ratios, mintot, n, d, rate)(wf) -> x[K]   src/multi_intersect.jl:26-104
  * ratios: HOST pointer [K]; xout: device [n][K]. status[n] != 0 where the
- * reference's boundary @assert (src/multi_intersect.jl:75-78) would fire. */
+ * reference's boundary @assert (src/multi_intersect.jl:75-78) would fire, or where the
+ * fit window of a threshold in between leaves the trace (the reference reads out of
+ * bounds there under @inbounds, :88-92). */
 int ldsp_multi_intersect(ldsp_ctx*, const float* x, int64_t n, int32_t L, double t_first, double dt,
                          const double* ratios, int32_t K, int32_t min_n, int32_t half_n, int32_t degree,
                          int32_t rate, float* xout, int32_t* status);

@@ -442,8 +442,13 @@ __global__ void __launch_bounds__(256) k_multi_intersect(const float* __restrict
       if (found) { ++ic; cnt = 0; }
     }
   }
+  if (tid == 0) s_rc = 0;
   __syncthreads();
-  if (tid == 0) s_rc = (s_ipos[0] - half_n >= 0 && s_ipos[K - 1] + half_n - 1 <= L - 1) ? 0 : LDSP_ERR_WINDOW;  // :75-78
+  // :75-78 asserts the first and the last window; the fit loop (:88-103) runs @inbounds, so a window of a threshold in
+  // between that leaves the trace (an unconfirmed threshold keeps position 1, n >= 2) would read out of bounds there.
+  // Every window is checked here and the trace flagged (as the oracle does).
+  for (int k = tid; k < K; k += NT)
+    if (s_ipos[k] - half_n < 0 || s_ipos[k] + half_n - 1 > L - 1) s_rc = LDSP_ERR_WINDOW;
   __syncthreads();
   const int w = 2 * half_n;
   const float* W = tab + K;

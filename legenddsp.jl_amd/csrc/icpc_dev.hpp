@@ -47,10 +47,17 @@ struct CuspZacDev {
   float q1, q2;                    // q, q^2
   float w_last;                    // sc * shape[Lf-1] (the tap that multiplies y[k] directly)
   float rho_sc;                    // ZAC: sc * acusp/apar (multiplies the parabola part)
-  // ZAC parabola part = double prefix sum of u[n] = sum_e zu_coef[e] * Dp[n - zu_shift[e]]
+  // ZAC parabola part = double prefix sum of u[n] = sum_e zu_coef[e] * (Dp[n - zu_shift[e]] - Dp[n - zu_shift_b[e]]).
+  // The second difference of the parabola taps weights Dp at nine shifts with coefficients of +-lt whose sum is zero; taken
+  // tap by tap, each product carries the rounding of lt * |Dp| (Dp keeps the level of the first sample for the whole trace)
+  // and the double prefix sum integrates that noise twice.  Summed by parts instead (Abel): differences of Dp between
+  // neighbouring shifts, which are small wherever the trace is flat, times the running sum of the coefficients.
   int32_t zu_n;
-  int32_t zu_shift[12];
+  int32_t zu_shift[12], zu_shift_b[12];
   float zu_coef[12];
+  // sum of the direct-form taps: the filter's response to a constant level.  The closed form runs on y - c (c = the level at
+  // the left edge of the pick-off window) and adds c * hsum back at the end, see cz_body / icpc_lean.hip phase 7
+  double hsum;
 };
 
 // trapezoid grid scan (ldsp_trap_grid_run): one parameter block in device memory

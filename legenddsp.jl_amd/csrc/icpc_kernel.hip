@@ -271,6 +271,28 @@ __device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4
     const int i0 = 4 * (tid + NT * r);
     yprev[r] = (i0 > 0) ? S.B0[i0 - 1] : 0.f;
   }
+  // Pivot (closed form only).  The parts of the closed form (flat top, sinh flanks, parabolas) each answer a constant level c
+  // under the filter with a multiple of c * Lf that cancels between them only in exact arithmetic: a trace whose baseline
+  // sits 2000 counts off zero (pile-up in the baseline window) loses 1e-4 of its ZAC energy to float rounding.  So the
+  // stage runs on y - cpiv, cpiv = the level at the left edge of the pick-off window, and adds cpiv * hsum back at the end
+  // (hsum = the sum of the direct-form taps; exact for any constant), which makes every trace look like a clean one.
+  float cpiv = 0.f, y0_piv = 0.f;
+  if constexpr (!DIRECT) {
+    const int Lf0 = (WANT_C ? P.cusp : P.zac).Lf;
+    const Pos pp = pos_add(ptx1, WANT_C ? P.cusp_pickoff : P.zac_pickoff);
+    const int ic = max(0, min(pp.ip - (Lf0 - 1), L - 1));
+    cpiv = S.B0[ic];
+    y0_piv = S.B0[0] - cpiv;
+    __syncthreads();   // every read of the unshifted y in B0 is done
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i0 = 4 * (tid + NT * r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[r][e] = (FULL || i0 + e < L) ? y[r][e] - cpiv : 0.f;
+      yprev[r] = (i0 > 0) ? yprev[r] - cpiv : 0.f;
+      *reinterpret_cast<float4*>(&S.B0[i0]) = make_float4(y[r][0], y[r][1], y[r][2], y[r][3]);
+    }
+  }
   // extremestats + SignalEstimator on filter outputs held in the LS view
   // (acc[m] = out[tid + NT*m]); f = 0 CUSP, 1 ZAC.          dsp_icpc.jl:170-171,177-178
   // Three steps with a barrier between them: finish_publish (per-wave estimator partial, the
@@ -327,8 +349,9 @@ __device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4
     for (int ww = 0; ww < NW; ++ww) s += S.wsum[(12 + f) * NW + ww];
     const float v = ford_inv(S.sl->fmx[f]);
     const int i = S.sl->imin[f];
-    put(f ? C_e_zac : C_e_cusp, (nout >= P.sig_est.npts) ? (float)s : NAN);
-    put(f ? C_e_zac_max : C_e_cusp_max, v);
+    const double back = (double)cpiv * (f ? P.zac.hsum : P.cusp.hsum);   // the pivot's share (estimator weights sum to one)
+    put(f ? C_e_zac : C_e_cusp, (nout >= P.sig_est.npts) ? (float)(s + back) : NAN);
+    put(f ? C_e_zac_max : C_e_cusp_max, (float)((double)v + back));
     put(f ? C_t_zac_max : C_t_cusp_max, P.t_first + P.dt * (float)(i + Lf - 1));
   };
 
@@ -374,12 +397,14 @@ __device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4
       // thread converts its own quads in place; otherwise T is re-derived by a scan of the
       // register-resident y.
       if constexpr (T_READY) {
-        const float y0 = S.B0[0];
+        const float y0 = y0_piv;               // (B0[0] is being rewritten by thread 0)
+        const float mec = -Z.eps * cpiv;       // B1 holds the exclusive prefix sum of the unshifted y: T'[i] = T[i] - cpiv*i
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           float4 t = *reinterpret_cast<const float4*>(&S.B1[4 * (tid + NT * r)]);
-          t.x = fmaf(Z.eps, t.x, y[r][0] - y0); t.y = fmaf(Z.eps, t.y, y[r][1] - y0);
-          t.z = fmaf(Z.eps, t.z, y[r][2] - y0); t.w = fmaf(Z.eps, t.w, y[r][3] - y0);
+          const float fi = (float)(4 * (tid + NT * r));
+          t.x = fmaf(Z.eps, t.x, y[r][0] - y0) + mec * fi; t.y = fmaf(Z.eps, t.y, y[r][1] - y0) + mec * (fi + 1.f);
+          t.z = fmaf(Z.eps, t.z, y[r][2] - y0) + mec * (fi + 2.f); t.w = fmaf(Z.eps, t.w, y[r][3] - y0) + mec * (fi + 3.f);
           *reinterpret_cast<float4*>(&S.B1[4 * (tid + NT * r)]) = t;
         }
       } else {
@@ -431,9 +456,9 @@ __device__ __forceinline__ void cz_body(SM& S, const IcpcDev& P, float (&y)[R][4
           const int nz = ZZ.zu_n;
           for (int e = 0; e < nz; ++e) {
             const float ce = ZZ.zu_coef[e];
-            const float* dp = &S.B1[tid - ZZ.zu_shift[e]];
+            const float *dp = &S.B1[tid - ZZ.zu_shift[e]], *dq = &S.B1[tid - ZZ.zu_shift_b[e]];
 #pragma unroll
-            for (int m = 0; m < SP; ++m) u[m] = fmaf(ce, dp[NT * m], u[m]);
+            for (int m = 0; m < SP; ++m) u[m] = fmaf(ce, dp[NT * m] - dq[NT * m], u[m]);
           }
 #pragma unroll
           for (int m = 0; m < SP; ++m) S.B0[tid + NT * m] = (tid + NT * m < L) ? u[m] : 0.f;
@@ -1167,6 +1192,21 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
           if (bi) *reinterpret_cast<unsigned long long*>(&S.bm[M_T0INV * NWORDS + wb]) = bi;
         }
       };
+      // A first leg of <= 3 samples (get_t0's 40 ns) is summed from y itself (B0): on the tail T is 1e7..1e8 and a difference
+      // of two of its float values is good to 1..8 counts — the size of the threshold the INVERTED trace is tested against there.
+      const float* ya = &S.B0[tid];
+      auto leg1 = [&](int n1, const float* a, float Tk, int m) {   // sum of the first leg's n1 samples of output row m
+        if (n1 <= 3) {
+          float l = ya[NT * m];
+          if (n1 >= 2) l += ya[NT * m + 1];
+          if (n1 >= 3) l += ya[NT * m + 2];
+          return l;
+        }
+        return a[NT * m] - Tk;
+      };
+      auto traw1 = [&](int n1, const float* a, const float* b, const float* c, float rr, float Tk, int m) {
+        return fmaf(c[NT * m] - b[NT * m], rr, -leg1(n1, a, Tk, m));
+      };
       static_assert(SP % 4 == 0, "row groups");
       const int nout_grp = inv_same ? nout_t0 : min(nout_t0, nout_t0i);
 #pragma unroll
@@ -1174,18 +1214,18 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
         if (NT * (m0 + 4) <= nout_grp) {
           // four rows wholly inside the trace and both output ranges: all their reads go out before the first comparison
           // (compiler fence), the LDS latency is paid once per group
-          float tk[4], ra[4], rb[4], rc[4], ia[4], ib[4], ic[4];
+          float tk[4], ra[4], rb[4], rc[4], ia[4], ib[4], ic[4];   // ra / ia: the first leg's sum
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            tk[q] = tb[NT * (m0 + q)];
-            ra[q] = t0a[NT * (m0 + q)]; rb[q] = t0b[NT * (m0 + q)]; rc[q] = t0c[NT * (m0 + q)];
-            if (!inv_same) { ia[q] = tia[NT * (m0 + q)]; ib[q] = tib[NT * (m0 + q)]; ic[q] = tic[NT * (m0 + q)]; }
+            tk[q] = (t0.n1 <= 3 && (inv_same || t0i.n1 <= 3)) ? 0.f : tb[NT * (m0 + q)];
+            ra[q] = leg1(t0.n1, t0a, tk[q], m0 + q); rb[q] = t0b[NT * (m0 + q)]; rc[q] = t0c[NT * (m0 + q)];
+            if (!inv_same) { ia[q] = leg1(t0i.n1, tia, tk[q], m0 + q); ib[q] = tib[NT * (m0 + q)]; ic[q] = tic[NT * (m0 + q)]; }
           }
           asm volatile("" ::: "memory");
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float o0 = fmaf(rc[q] - rb[q], rr0, -(ra[q] - tk[q]));
-            const float o0i = inv_same ? o0 : fmaf(ic[q] - ib[q], rri, -(ia[q] - tk[q]));
+            const float o0 = fmaf(rc[q] - rb[q], rr0, -ra[q]);
+            const float o0i = inv_same ? o0 : fmaf(ic[q] - ib[q], rri, -ia[q]);
             emit(m0 + q, o0, o0i);
           }
           continue;
@@ -1195,11 +1235,11 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
           const int k = tid + NT * m;
           const float Tk = tb[NT * m];
           float o0 = NAN, o0i = NAN;   // NaN: both comparisons false for rows/lanes outside the output range
-          if (NT * (m + 1) <= nout_t0) o0 = traw(t0a, t0b, t0c, rr0, Tk, m);
-          else if (NT * m < nout_t0) { o0 = traw(t0a, t0b, t0c, rr0, Tk, m); o0 = (k < nout_t0) ? o0 : NAN; }
+          if (NT * (m + 1) <= nout_t0) o0 = traw1(t0.n1, t0a, t0b, t0c, rr0, Tk, m);
+          else if (NT * m < nout_t0) { o0 = traw1(t0.n1, t0a, t0b, t0c, rr0, Tk, m); o0 = (k < nout_t0) ? o0 : NAN; }
           if (inv_same) o0i = o0;
-          else if (NT * (m + 1) <= nout_t0i) o0i = traw(tia, tib, tic, rri, Tk, m);
-          else if (NT * m < nout_t0i) { o0i = traw(tia, tib, tic, rri, Tk, m); o0i = (k < nout_t0i) ? o0i : NAN; }
+          else if (NT * (m + 1) <= nout_t0i) o0i = traw1(t0i.n1, tia, tib, tic, rri, Tk, m);
+          else if (NT * m < nout_t0i) { o0i = traw1(t0i.n1, tia, tib, tic, rri, Tk, m); o0i = (k < nout_t0i) ? o0i : NAN; }
           emit(m, o0, o0i);
         }
       }

@@ -705,11 +705,25 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       const float thr0 = P.t0_thr * t0.navg;
       const int nout = L - t0.flen + 1;
       uint32_t acc = 0u;   // lanes 0..31: words of the t0 mask, 32..63: of the inverted one (rows beyond the output range stay 0)
+      // A first leg of <= 3 samples (get_t0's 40 ns) is summed from y itself: on the tail T is 1e7..1e8 and a difference of two
+      // of its float values is good to 1..8 counts — the size of the threshold the INVERTED trace is tested against there.
+      const int n1s = t0.n1;
+      const bool short1 = n1s <= 3;
+      const float* ya = &S.A[tid];
 #pragma unroll
       for (int m = 0; m < SP; m += 2) {
         if (NT * m >= nout) continue;   // pair beyond the output range
-        const f2 Tk = rd2(tb, m), a = rd2(ta, m), b = rd2(tbb, m), c = rd2(tc, m);
-        f2 o = fma2(c - b, rr, Tk - a);
+        const f2 b = rd2(tbb, m), c = rd2(tc, m);
+        f2 ml;   // minus the first leg's sum
+        if (short1) {
+          f2 l = rd2(ya, m);
+          if (n1s >= 2) l = l + rd2(ya + 1, m);
+          if (n1s >= 3) l = l + rd2(ya + 2, m);
+          ml = splat(0.f) - l;
+        } else {
+          ml = rd2(tb, m) - rd2(ta, m);
+        }
+        f2 o = fma2(c - b, rr, ml);
         if (NT * (m + 2) > nout) {   // the pair that holds the end of the output range (and pairs beyond it)
           o.x = (tid + NT * m < nout) ? o.x : NAN; o.y = (tid + NT * (m + 1) < nout) ? o.y : NAN;   // NaN: both comparisons false
         }
@@ -925,8 +939,9 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
         int i0c, i0z; float uc, uz;
         est_window(P.sig_est, pc_, nout_cz, &i0c, &uc);
         est_window(P.sig_est, pz2, nout_cz, &i0z, &uz);
-        if (lane == 0) { S.misc[8] = __int_as_float(i0c); S.misc[9] = uc; S.misc[10] = __int_as_float(i0z); S.misc[11] = uz; }
-      }
+        // the level at the left edge of the pick-off window: the CUSP / ZAC stage runs on y - cpiv (see there)
+        if (lane == 0) { S.misc[8] = __int_as_float(i0c); S.misc[9] = uc; S.misc[10] = __int_as_float(i0z); S.misc[11] = uz; S.misc[12] = S.A[i0c]; }
+      } else if (lane == 0) S.misc[12] = 0.f;
     }
     if (wave == 1 % NW || wave == 2 % NW) {
       const bool lq = (NW > 2) ? wave == 2 : false;
@@ -966,15 +981,26 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
     float yprev[R];   // y just before each of the thread's quads (for d[i] = y[i] - a*y[i-1])
 #pragma unroll
     for (int r = 0; r < R; ++r) { const int i0 = 4 * (tid + NT * r); yprev[r] = (i0 > 0) ? S.A[i0 - 1] : 0.f; }
+    // Pivot.  The parts of the closed form (flat top, sinh flanks, parabolas) each answer a constant level c under the filter
+    // with a multiple of c * Lf that cancels between them only in exact arithmetic: a trace whose baseline sits 2000 counts
+    // off zero (pile-up in the baseline window) loses 1e-4 of its ZAC energy to float rounding.  So the stage runs on
+    // y' = y - cpiv, cpiv = the level at the left edge of the pick-off window (any constant is exact mathematically:
+    // out = out' + cpiv * hsum, hsum = the sum of the direct-form taps), which makes every trace look like a clean one.
+    // y' is never materialised:  Dp' = Dp - eps*cpiv*i,  d' = d - eps*cpiv,  the taps on y[k] fold cpiv into their fma.
+    const float cpiv = S.misc[12];
+    const float mec = -Z.eps * cpiv;
     // ---- Dp[i] = y[i] - y[0] + eps*T[i] -> B, in place of T (each thread converts its own quads)
     {
       const float y0 = S.A[0];
       const f2 e2 = splat(Z.eps), y02 = splat(y0);
+      const float bf = (float)(4 * tid);   // T is the exclusive prefix sum: T'[i] = T[i] - cpiv*i
+      const f2 l01 = splat(mec) * mk2(bf, bf + 1.f), l23 = splat(mec) * mk2(bf + 2.f, bf + 3.f);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         f4 t = *reinterpret_cast<const f4*>(&S.B[4 * (tid + NT * r)]);
-        t.xy = fma2(e2, t.xy, y[r].xy - y02);
-        t.zw = fma2(e2, t.zw, y[r].zw - y02);
+        const f2 lr = splat(mec * (float)(4 * NT * r));
+        t.xy = fma2(e2, t.xy, y[r].xy - y02) + (l01 + lr);
+        t.zw = fma2(e2, t.zw, y[r].zw - y02) + (l23 + lr);
         *reinterpret_cast<f4*>(&S.B[4 * (tid + NT * r)]) = t;
       }
     }
@@ -983,8 +1009,8 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const f2 p0 = mk2(yprev[r], y[r].x), p1 = mk2(y[r].y, y[r].z);
-      d[r][0] = fma2(splat(Z.eps), p0, y[r].xy - p0);
-      d[r][1] = fma2(splat(Z.eps), p1, y[r].zw - p1);
+      d[r][0] = fma2(splat(Z.eps), p0, (y[r].xy - p0) + splat(mec));
+      d[r][1] = fma2(splat(Z.eps), p1, (y[r].zw - p1) + splat(mec));
       if (r == 0 && tid == 0) d[0][0].x = 0.f;
     }
     __syncthreads();
@@ -994,12 +1020,13 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
     f2 ac[SP / 2], dz[SP / 2];
     {
       const f2 dwl = splat(ZZ.w_last - Z.w_last), wl = splat(Z.w_last), sc = splat(Z.sc);
+      const f2 mwlc = splat(-Z.w_last * cpiv), mdwlc = splat(-(ZZ.w_last - Z.w_last) * cpiv);
       const float *ya = &S.A[tid], *dpa = &S.B[tid + Lf - 1 - lt], *dpb = &S.B[tid + Lf - 1 - f1];
 #pragma unroll
       for (int m = 0; m < SP; m += 2) {
         const f2 yk = rd2(ya, m), pa = rd2(dpa, m), pb = rd2(dpb, m);
-        ac[m / 2] = fma2(sc, pa - pb, wl * yk);
-        dz[m / 2] = dwl * yk;
+        ac[m / 2] = fma2(sc, pa - pb, fma2(wl, yk, mwlc));
+        dz[m / 2] = fma2(dwl, yk, mdwlc);
         pin(ac[m / 2]); pin(dz[m / 2]);
         if ((m & 2) == 2) __builtin_amdgcn_sched_barrier(0);   // at most two pairs of rows of loads in flight (register pressure)
       }
@@ -1009,9 +1036,9 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       const int nz = ZZ.zu_n;
       for (int e = 0; e < nz; ++e) {
         const f2 ce = splat(ZZ.zu_coef[e]);
-        const float* dp = &S.B[tid - ZZ.zu_shift[e]];
+        const float *dp = &S.B[tid - ZZ.zu_shift[e]], *dq = &S.B[tid - ZZ.zu_shift_b[e]];
 #pragma unroll
-        for (int m = 0; m < SP; m += 2) { u[m / 2] = fma2(ce, rd2(dp, m), u[m / 2]); pin(u[m / 2]); }
+        for (int m = 0; m < SP; m += 2) { u[m / 2] = fma2(ce, rd2(dp, m) - rd2(dq, m), u[m / 2]); pin(u[m / 2]); }
       }
 #pragma unroll
       for (int m = 0; m < SP; m += 2) { S.A[tid + NT * m] = u[m / 2].x; S.A[tid + NT * (m + 1)] = u[m / 2].y; }   // own elements: race-free
@@ -1208,8 +1235,9 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       for (int ww = 0; ww < NW; ++ww) s += S.wsum[(W_CZ + f) * NW + ww];
       const float v = ford_inv(S.sl->fmx[f ? FX_ZAC : FX_CUSP]);
       const int i = S.sl->imin[f ? IM_ZAC : IM_CUSP];
-      S.outv[f ? C_e_zac : C_e_cusp] = (nout >= P.sig_est.npts) ? s : NAN;
-      S.outv[f ? C_e_zac_max : C_e_cusp_max] = v;
+      const double back = (double)cpiv * (f ? ZZ.hsum : Z.hsum);   // the pivot's share of the output (estimator weights sum to one)
+      S.outv[f ? C_e_zac : C_e_cusp] = (nout >= P.sig_est.npts) ? (float)((double)s + back) : NAN;
+      S.outv[f ? C_e_zac_max : C_e_cusp_max] = (float)((double)v + back);
       S.outv[f ? C_t_zac_max : C_t_cusp_max] = P.t_first + P.dt * (float)(i + Lf - 1);
     }
   }

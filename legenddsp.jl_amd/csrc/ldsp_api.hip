@@ -253,6 +253,13 @@ static bool make_cuspzac(const ldsp_cuspzac& p, bool zac, CuspZacDev& d) {
   const double rho = zac ? acusp / apar : 0.0;
   d.w_last = (float)(sc * (cusp[g.Lf - 1] - rho * par[g.Lf - 1]));
   d.rho_sc = (float)(rho * sc);
+  {
+    std::vector<double> taps;
+    hm::cuspzac_taps(p, zac, taps);
+    double hs = 0;
+    for (double t : taps) hs += t;
+    d.hsum = hs;
+  }
   if (!zac) return true;
   // Second difference of the parabola kernel restricted to taps 0..Lf-2 (the last
   // tap multiplies y[k] directly): constant 2 on two ranges plus a few edge taps.
@@ -266,9 +273,18 @@ static bool make_cuspzac(const ldsp_cuspzac& p, bool zac, CuspZacDev& d) {
     double c = (sft < g.Lf + 2 ? D2[sft] : 0.0) - (sft >= 1 ? D2[sft - 1] : 0.0);
     if (std::fabs(c) > 1e-9) terms.push_back({sft, c});
   }
-  if (terms.size() > 12) return false;
-  d.zu_n = (int)terms.size();
-  for (size_t e = 0; e < terms.size(); ++e) { d.zu_shift[e] = terms[e].first; d.zu_coef[e] = (float)terms[e].second; }
+  // summation by parts: sum_e c_e Dp[n-s_e] = sum_e R_e (Dp[n-s_e] - Dp[n-s_{e+1}]),  R_e = c_0 + .. + c_e  (R_last = 0)
+  if (terms.size() < 2 || terms.size() > 13) return false;
+  double run = 0, total = 0;
+  for (auto& t : terms) total += t.second;
+  if (std::fabs(total) > 1e-6) return false;
+  d.zu_n = 0;
+  for (size_t e = 0; e + 1 < terms.size(); ++e) {
+    run += terms[e].second;
+    if (std::fabs(run) <= 1e-9) continue;
+    d.zu_shift[d.zu_n] = terms[e].first; d.zu_shift_b[d.zu_n] = terms[e + 1].first; d.zu_coef[d.zu_n] = (float)run;
+    ++d.zu_n;
+  }
   return true;
 }
 

@@ -1,13 +1,30 @@
-"""Column-wise comparison of the HIP dsp_icpc table with the CPU oracle.
+"""Column-wise comparison of the HIP dsp_icpc table with the CPU oracle: the per-column error budgets.
 
-Tolerances (float32 compute vs float64 oracle), per column class:
-  stat / energy columns : |a-b| <= atol_c + RTOL*|b|, RTOL = 2e-5
-  crossing times (us)   : |a-b| <= 5e-4 us (0.03 sample of 16 ns)
-  argmax times (ns)     : equal, or the two maxima tie within the energy tolerance
-  integer columns       : exact
-A threshold decision |y - thr| below float32 resolution can legitimately flip;
-such traces show up as isolated outliers and are reported, and the tests bound
-their fraction (FLIP_FRAC).
+float32 compute against the float64 oracle.  A column's budget is |a-b| <= atol_c + RTOL*|b| plus, where a column
+inherits the rounding of another quantity, that quantity's share (written next to the rule):
+
+  stat / energy columns   atol_c + RTOL*|b|, RTOL = 2e-5
+  sigma columns           + 1.5e-6 * |mean level|: sqrt(E[d^2]-E[d]^2) of a (near) noise-free window is the square root of a
+                          cancellation, the float32 rounding of the samples themselves (the oracle sees 2e-4 on a flat
+                          1000-count baseline, the kernel's clamped variance gives 0)
+  tail_tau                compared as the decay rate 1/tau (|1/a-1/b| <= 1e-10): a flat tail gives tau = -1/slope anywhere
+                          between 1e15 and infinity
+  crossing times (us)     5e-4 us (0.03 sample of 16 ns)
+  drift_time              0.6 ns (the same 0.03 sample, twice)
+  qdrift / lq             + 2*e_max*|dt_ref|/dt: the second difference of the integrator moves with its reference time (t0 /
+                          t80) by at most 2*e_max per sample, and the two sides evaluate it at THEIR reference time
+  arg-max times (ns)      equal, or the two maxima tie within the energy tolerance
+  a_raw                   the parabola through the arg-max of the one-sample derivative: on a noise-free trace the
+                          derivative has a plateau of (nearly) equal samples and the arg-max is decided by the last bit;
+                          accepted when the value equals the parabola through ANOTHER sample of that plateau (needs the
+                          trace: compare(..., wf=, params=, orc=))
+  integer columns         exact; inTrace_n (a count of ~10..150 noise crossings of a threshold that is itself a float32
+                          sigma) may differ by <= 3 on a fraction of rows <= max(FLIP_FRAC, 2e-3 * mean count):
+                          about one decision in a thousand falls within the float32 rounding of the filtered sample
+
+A threshold decision |y - thr| below float32 resolution can legitimately flip (a crossing confirmed or not, a run one
+sample longer); such traces show up as isolated outliers in the time columns and everything derived from them, and the
+tests bound their fraction per column (FLIP_FRAC).
 """
 import numpy as np
 
@@ -23,7 +40,7 @@ INT_COLS = _abi.ICPC_I32_COLS
 ATOL = {
     "blmean": 2e-3, "blsigma": 2e-4, "blslope": 1e-8, "bloffset": 2e-3,
     "tailmean": 0.05, "tailsigma": 5e-3, "tailslope": 2e-7, "tailoffset": 0.05,
-    "tail_tau": 50.0, "tail_mean": 2e-6, "tail_sigma": 2e-6,
+    "tail_tau": 50.0, "tail_mean": 2e-6, "tail_sigma": 5e-6,
     "e_max": 2e-3, "e_min": 2e-3,
     "e_10410": 0.05, "e_535": 0.05, "e_313": 0.05, "e_10410_inv": 0.05, "e_313_inv": 0.1,
     "e_trap": 0.05, "e_cusp": 0.1, "e_zac": 0.1, "e_trap_max": 0.05, "e_cusp_max": 0.1, "e_zac_max": 0.1,
@@ -31,35 +48,96 @@ ATOL = {
     "qdrift": 3.0, "lq": 3.0, "a_sg": 5e-3, "a_60": 5e-3, "a_100": 5e-3, "a_raw": 5e-3,
     "drift_time": 0.6, "inTrace_intersect": 0.6,
 }
+SIGMA_LEVEL = {"blsigma": "blmean", "tailsigma": "tailmean"}     # sigma column -> the level its samples are rounded at
+QDRIFT_REF = {"qdrift": "t0", "lq": "t80"}
+INTRACE_MAX_DIFF = 3
 
 
-def compare(gpu: dict, ora: dict, verbose=False):
-    """gpu / ora: dict column -> numpy array.  Returns (report_lines, worst_bad_fraction)."""
+def _extrema3points(y1, y2, y3):      # reference src/interpolation.jl:8-10 (three equal samples: the parabola is the level itself)
+    a = y3 - 4 * y2 + 3 * y1
+    den = 8 * (y3 - 2 * y2 + y1)
+    return y2 if abs(den) <= 1e-12 * max(1.0, abs(y2)) else y1 - a * a / den
+
+
+def _a_raw_tie(rows, gpu_vals, ora, wf, params, orc):
+    """rows whose GPU a_raw equals the parabola through another sample of the derivative's plateau (see the module text)."""
+    ok = np.zeros(len(rows), dtype=bool)
+    dt, t_first = params.dt, params.t_first
+    frm, until = int(round((params.cur_left - t_first) / dt)), int(round((params.cur_right - t_first) / dt))
+    for n, (i, g) in enumerate(zip(rows, gpu_vals)):
+        y = orc.invcr(np.asarray(wf[i], dtype=np.float64) - ora["blmean"][i], params.pz_c)
+        d = np.asarray(orc.derivative(y, 1.0))
+        win = d[frm:until + 1]
+        top = win.max()
+        tie = 4e-7 * np.abs(y[frm:until + 2]).max() + 1e-3          # two roundings of the samples the difference is taken of
+        for j in np.nonzero(win >= top - tie)[0]:
+            v = _extrema3points(win[j - 1], win[j], win[j + 1]) if 0 < j < len(win) - 1 else win[j]
+            if np.isfinite(v) and abs(g - v) <= ATOL["a_raw"] + RTOL * abs(v) + 2 * tie:
+                ok[n] = True
+                break
+    return ok
+
+
+def bad_mask(c, gpu, ora, wf=None, params=None, orc=None):
+    """-> (bad, err): bad[i] = row i of column c is outside its budget (module text), err = |gpu - oracle|."""
+    a = np.asarray(gpu[c], dtype=np.float64)
+    b = np.asarray(ora[c], dtype=np.float64)
+    both_nan = np.isnan(a) & np.isnan(b)
+    err = np.abs(a - b)
+    if c == "inTrace_n":
+        bad = (err > INTRACE_MAX_DIFF) & ~both_nan
+    elif c in INT_COLS:
+        bad = (a != b) & ~both_nan
+    elif c in TIME_US:
+        bad = ~(err <= 5e-4) & ~both_nan
+    elif c in TIME_MAX:
+        bad = ~(err <= 1e-3) & ~both_nan
+        mcol = c.replace("t_", "e_")     # near-tie: accept when the corresponding maxima agree
+        tie = np.abs(np.asarray(gpu[mcol], dtype=np.float64) - ora[mcol]) <= ATOL[mcol] + RTOL * np.abs(ora[mcol])
+        bad &= ~tie
+    else:
+        tol = ATOL[c] + RTOL * np.abs(b)
+        if c in SIGMA_LEVEL:
+            tol = tol + 1.5e-6 * np.abs(np.asarray(ora[SIGMA_LEVEL[c]], dtype=np.float64))
+        if c in QDRIFT_REF:
+            tr = QDRIFT_REF[c]
+            d_ref = np.abs(np.asarray(gpu[tr], dtype=np.float64) - ora[tr]) * params_unit_per_us(params) / params_dt(params)
+            tol = tol + 2.0 * np.abs(np.asarray(ora["e_max"], dtype=np.float64)) * d_ref
+        bad = ~(err <= tol) & ~both_nan
+        if c == "tail_tau":
+            with np.errstate(divide="ignore", invalid="ignore"):
+                bad &= ~(np.abs(1.0 / a - 1.0 / b) <= 1e-10)
+        if c == "a_raw" and bad.any() and wf is not None and params is not None and orc is not None:
+            rows = np.nonzero(bad)[0]
+            bad[rows[_a_raw_tie(rows, a[rows], ora, wf, params, orc)]] = False
+    return bad, err
+
+
+def params_dt(params):
+    return 16.0 if params is None else params.dt
+
+
+def params_unit_per_us(params):
+    return 1000.0 if params is None else params.unit_per_us
+
+
+def compare(gpu: dict, ora: dict, verbose=False, wf=None, params=None, orc=None):
+    """gpu / ora: dict column -> numpy array.  Returns (report_lines, worst_bad_fraction).
+    wf (host array [n, L]), params (ldsp_icpc_params) and orc (the oracle module) enable the a_raw plateau rule and the
+    exact time axis for the qdrift / lq rule (default: dt = 16 ns, 1000 units per us)."""
     lines, worst = [], 0.0
     n = len(next(iter(ora.values())))
     for c in _abi.ICPC_COLS:
-        a = np.asarray(gpu[c], dtype=np.float64)
+        bad, err = bad_mask(c, gpu, ora, wf, params, orc)
         b = np.asarray(ora[c], dtype=np.float64)
-        both_nan = np.isnan(a) & np.isnan(b)
-        if c in INT_COLS:
-            bad = (a != b) & ~both_nan
-            err = np.abs(a - b)
-        elif c in TIME_US:
-            err = np.abs(a - b)
-            bad = ~(err <= 5e-4) & ~both_nan
-        elif c in TIME_MAX:
-            err = np.abs(a - b)
-            bad = ~(err <= 1e-3) & ~both_nan
-            # near-tie: accept when the corresponding maxima agree
-            mcol = c.replace("t_", "e_")
-            tie = np.abs(np.asarray(gpu[mcol], dtype=np.float64) - ora[mcol]) <= ATOL[mcol] + RTOL * np.abs(ora[mcol])
-            bad &= ~tie
-        else:
-            err = np.abs(a - b)
-            bad = ~(err <= ATOL[c] + RTOL * np.abs(b)) & ~both_nan
         frac = bad.sum() / max(n, 1)
+        if c == "inTrace_n":      # small differences: a separate, count-dependent budget on the fraction of rows
+            soft = ((err > 0) & ~bad).sum() / max(n, 1)
+            allowed = max(FLIP_FRAC, 2e-3 * float(np.nanmean(b))) if n else FLIP_FRAC
+            if soft > allowed:
+                frac = max(frac, soft)
         worst = max(worst, frac)
-        e = err[~both_nan & np.isfinite(err)]
+        e = err[np.isfinite(err)]
         scale = np.nanmax(np.abs(b)) if np.isfinite(b).any() else 0
         lines.append(f"{c:20s} max|err|={e.max() if e.size else 0:11.4g}  ref scale={scale:11.4g}  bad={int(bad.sum())}/{n}")
     return lines, worst

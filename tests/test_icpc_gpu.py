@@ -141,18 +141,27 @@ def test_trace_lengths_that_do_not_fill_the_tile(orc, Lx):
     assert worst <= 0.03, "\n".join(lines)
 
 
-def test_two_launch_form_equals_fused(params):
-    """`two_kernel` = 1 (icpc_kernel + icpc_cz_kernel, the fall-back form) gives the fused launch's table."""
+def test_two_launch_form_equals_fused(params, orc):
+    """`two_kernel` = 1 (icpc_kernel + icpc_cz_kernel, the fall-back form) gives the fused generic launch's table to the
+    last bits, and the lean kernel's table within the oracle budgets (a different summation order)."""
     wf = ldsp.synth.hpge_batch(96, L, device="cuda", seed=17)
-    fused = _run(wf, params)
+    fused = _run(wf, params, generic=1)
+    lean = _run(wf, params)
     ctx = ldsp.default_context()
     ctx.set_option("two_kernel", 1)
     try:
         two = _run(wf, params)
     finally:
         ctx.set_option("two_kernel", 0)
+    fused64 = {k: np.asarray(v, dtype=np.float64) for k, v in fused.items()}
     for c in ldsp._abi.ICPC_COLS:
-        np.testing.assert_allclose(two[c], fused[c], rtol=3e-6, atol=1e-3, equal_nan=True, err_msg=c)
+        if c in parity.TIME_MAX:      # an arg-max may sit on a tie that the two summation orders break differently
+            bad, _ = parity.bad_mask(c, two, fused64)
+            assert bad.sum() == 0, c
+        else:
+            np.testing.assert_allclose(two[c], fused[c], rtol=3e-6, atol=1e-3, equal_nan=True, err_msg=c)
+    lines, worst = parity.compare(two, {k: np.asarray(v, dtype=np.float64) for k, v in lean.items()})
+    assert worst <= parity.FLIP_FRAC, "\n".join(lines)
 
 
 def test_long_traces_16384(orc):

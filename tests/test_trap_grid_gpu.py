@@ -113,7 +113,7 @@ def test_qc_and_qdrift_flt_optimization_agree_with_the_fused_chain():
     full = {k: v for k, v in ldsp.table_columns(ldsp.icpc_run(sig, p)).items()}
     qc = ldsp.dsp_qc_flt_optimization(wvfs, cfg, 500 * ldsp.us)
     torch.testing.assert_close(qc["blmean"], full["blmean"], rtol=0, atol=0)          # same summation, same pivot
-    torch.testing.assert_close(qc["blslope"], full["blslope"], rtol=1e-6, atol=1e-12)
+    torch.testing.assert_close(qc["blslope"], full["blslope"], rtol=1e-4, atol=2e-11)   # the lean kernel finishes the window in float32 (rcp / sqrt)
     # t50 here crosses half the maximum of the pole-zero corrected trace (:46), dsp_icpc half the raw maximum minus
     # baseline (dsp_icpc.jl:111,133): a few ns apart, and the flat-top energy follows within 1e-3
     torch.testing.assert_close(qc["t50"], full["t50"], rtol=0, atol=0.05)

@@ -23,8 +23,9 @@ for it in range(nconf):
     wf = fuzz_cases.icpc_traces(n, L, it, noise)
     tab = ldsp.icpc_run(wf, p); torch.cuda.synchronize()
     gpu = {k: v.cpu().numpy() for k, v in ldsp.table_columns(tab).items()}
-    ora = orc.dsp_icpc(wf.cpu().numpy(), p, nthreads=16, strict=False)
-    lines, worst = parity.compare(gpu, ora)
+    host = wf.cpu().numpy()
+    ora = orc.dsp_icpc(host, p, nthreads=16, strict=False)
+    lines, worst = parity.compare(gpu, ora, wf=host, params=p, orc=orc)
     bad = [l for l in lines if not l.rstrip().endswith(f"bad=0/{n}")]
     bad_total += len(bad)
     print(f"[{it}] {descr}  worst bad fraction {worst:.4f}")
