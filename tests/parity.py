@@ -19,8 +19,9 @@ inherits the rounding of another quantity, that quantity's share (written next t
                           accepted when the value equals the parabola through ANOTHER sample of that plateau (needs the
                           trace: compare(..., wf=, params=, orc=))
   integer columns         exact; inTrace_n (a count of ~10..150 noise crossings of a threshold that is itself a float32
-                          sigma) may differ by <= 3 on a fraction of rows <= max(FLIP_FRAC, 2e-3 * mean count):
-                          about one decision in a thousand falls within the float32 rounding of the filtered sample
+                          sigma) may differ by <= 3 on a fraction of rows <= max(FLIP_FRAC, 6e-3 * mean count):
+                          at a noise sigma of 1 count the float32 rounding of the Savitzky-Golay output (2e-4) is 0.2 % of its
+                          noise, measured 4.6 decisions in a thousand flip (fuzz case 13); fewer at the usual noise
 
 A threshold decision |y - thr| below float32 resolution can legitimately flip (a crossing confirmed or not, a run one
 sample longer); such traces show up as isolated outliers in the time columns and everything derived from them, and the
@@ -131,13 +132,16 @@ def compare(gpu: dict, ora: dict, verbose=False, wf=None, params=None, orc=None)
         bad, err = bad_mask(c, gpu, ora, wf, params, orc)
         b = np.asarray(ora[c], dtype=np.float64)
         frac = bad.sum() / max(n, 1)
+        note = ""
         if c == "inTrace_n":      # small differences: a separate, count-dependent budget on the fraction of rows
-            soft = ((err > 0) & ~bad).sum() / max(n, 1)
-            allowed = max(FLIP_FRAC, 2e-3 * float(np.nanmean(b))) if n else FLIP_FRAC
-            if soft > allowed:
-                frac = max(frac, soft)
+            soft_rows = (err > 0) & ~bad
+            allowed = max(FLIP_FRAC, 6e-3 * float(np.nanmean(b))) if n else FLIP_FRAC
+            note = f"  (differ by <= {INTRACE_MAX_DIFF}: {int(soft_rows.sum())}/{n}, allowed {allowed:.3f}, mean count {float(np.nanmean(b)):.1f})"
+            if soft_rows.sum() / max(n, 1) > allowed:
+                bad = bad | soft_rows
+                frac = bad.sum() / max(n, 1)
         worst = max(worst, frac)
         e = err[np.isfinite(err)]
         scale = np.nanmax(np.abs(b)) if np.isfinite(b).any() else 0
-        lines.append(f"{c:20s} max|err|={e.max() if e.size else 0:11.4g}  ref scale={scale:11.4g}  bad={int(bad.sum())}/{n}")
+        lines.append(f"{c:20s} max|err|={e.max() if e.size else 0:11.4g}  ref scale={scale:11.4g}  bad={int(bad.sum())}/{n}" + note)
     return lines, worst

@@ -26,7 +26,7 @@ for it in range(nconf):
     host = wf.cpu().numpy()
     ora = orc.dsp_icpc(host, p, nthreads=16, strict=False)
     lines, worst = parity.compare(gpu, ora, wf=host, params=p, orc=orc)
-    bad = [l for l in lines if not l.rstrip().endswith(f"bad=0/{n}")]
+    bad = [l for l in lines if f"bad=0/{n}" not in l]
     bad_total += len(bad)
     print(f"[{it}] {descr}  worst bad fraction {worst:.4f}")
     for l in bad:
