@@ -213,6 +213,68 @@ __device__ __forceinline__ void wacc_lane(const WAcc& a, int tid, float ic, floa
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// ---- cross-wave prefix sums of the wave-row totals.  A wave-row is the 256 samples a wave holds of one register row; its
+// total part[4*w + r] comes out of the in-wave DPP scan.  ONE wave turns the R*NW totals (time order j = r*NW + w) into
+// exclusive prefixes in double and leaves each wave what it needs as floats, laid out [w][r] (one 16-byte read per wave);
+// the other waves wait at the barrier that follows instead of running the same 60-instruction double scan eight times.
+template <int NW>
+__device__ __forceinline__ double row_prefix_f64(const float* part, int lane, double* total) {
+  const int jr = lane / NW, jw = lane - jr * NW;   // lane j <-> wave-row (r = jr, w = jw)
+  const double pvv = (lane < R * NW) ? (double)part[4 * jw + jr] : 0.0;
+  const double pinc = wave_incl_scan_sum_f64(pvv);
+  if (total) *total = readlane_d(pinc, R * NW - 1);
+  return pinc - pvv;
+}
+// InvCRFilter y = x + c*cumsum(x) (dsp_icpc.jl:119-120): c * (sum of x before the wave-row) as a float per wave-row
+template <int NW>
+__device__ __forceinline__ void pz_offsets_scan(const float* part, float* scn, double pz_c64, int wave, int lane) {
+  if (wave != 0) return;
+  const double ex = row_prefix_f64<NW>(part, lane, nullptr);
+  const int jr = lane / NW, jw = lane - jr * NW;
+  if (lane < R * NW) scn[4 * jw + jr] = (float)(pz_c64 * ex);
+}
+template <int NW>
+__device__ __forceinline__ void pz_apply(f4 (&x)[R], const float (&inc)[R], const float (&tot)[R], const float* scn, float pz_c, int wave) {
+  const f4 co = *reinterpret_cast<const f4*>(&scn[4 * wave]);
+  const float cw[R] = {co.x, co.y, co.z, co.w};
+  const f2 c2 = splat(pz_c);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float coff = fmaf(pz_c, inc[r] - tot[r], cw[r]);   // c * (sum of x before this lane's quad)
+    const float r1 = x[r].x + x[r].y, r2 = r1 + x[r].z, r3 = r2 + x[r].w;   // running sums inside the quad
+    const f2 cf = splat(coff);
+    x[r].xy = fma2(c2, mk2(x[r].x, r1), x[r].xy + cf);
+    x[r].zw = fma2(c2, mk2(r2, r3), x[r].zw + cf);
+  }
+}
+// T = exclusive prefix sum of y: the sum before each wave-row split into hi = float(sum), lo = float(sum - hi); T[L] -> *t_end
+template <int NW>
+__device__ __forceinline__ void t_offsets_scan(const float* part, float* hilo, float* t_end, int wave, int lane) {
+  if (wave != 0) return;
+  double total;
+  const double ex = row_prefix_f64<NW>(part, lane, &total);
+  const int jr = lane / NW, jw = lane - jr * NW;
+  const float hi = (float)ex;
+  if (lane < R * NW) { hilo[4 * jw + jr] = hi; hilo[R * NW + 4 * jw + jr] = (float)(ex - (double)hi); }
+  if (lane == 0) *t_end = (float)total;
+}
+// T of a quad = hi + (lo + (sum inside the wave-row before the sample)): one rounding at the magnitude of T
+template <int NT, typename LdsF>
+__device__ __forceinline__ void t_rows_store(const f4 (&y)[R], const float (&tin)[R], const float (&tot)[R], const float* hilo, LdsF* B, int tid, int wave) {
+  constexpr int NW = NT / 64;
+  const f4 h = *reinterpret_cast<const f4*>(&hilo[4 * wave]), l = *reinterpret_cast<const f4*>(&hilo[R * NW + 4 * wave]);
+  const float hw[R] = {h.x, h.y, h.z, h.w}, lw[R] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float p0 = tin[r] - tot[r];   // sum of the wave-row's samples before this lane's quad (exclusive DPP scan)
+    const float p1 = p0 + y[r].x, p2 = p1 + y[r].y, p3 = p2 + y[r].z;
+    const f2 h2 = splat(hw[r]), lo2 = splat(lw[r]);
+    const f2 ta = h2 + (lo2 + mk2(p0, p1)), tb = h2 + (lo2 + mk2(p2, p3));
+    *reinterpret_cast<f4*>(&B[4 * (tid + NT * r)]) = (f4){ta.x, ta.y, tb.x, tb.y};
+  }
+}
+
+
 template <int NT, int M>
 __global__ void __launch_bounds__(NT, 4)
 icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOutDev out, const float* __restrict__ ext_bl,
@@ -396,16 +458,9 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
   }
   STAMP(3); DSTOP(3);
   __syncthreads();
-  // exclusive prefix (double) of the R*NW wave-row totals in time order j = r*NW + w, by every wave
-  auto wave_row_offsets = [&](const float* part, double (&off)[R], double* total) {
-    const int jr = lane / NW, jw = lane - jr * NW;   // lane j <-> wave-row (r = jr, w = jw)
-    const double pvv = (lane < R * NW) ? (double)part[4 * jw + jr] : 0.0;
-    const double pinc = wave_incl_scan_sum_f64(pvv);
-    const double pexc = pinc - pvv;
-#pragma unroll
-    for (int r = 0; r < R; ++r) off[r] = readlane_d(pexc, r * NW + wave);
-    if (total) *total = readlane_d(pinc, R * NW - 1);
-  };
+  // c * (sum of x before each wave-row), by wave 0 (pz_offsets_scan); the scratch is the ZAC stage's dpart, unused until then
+  float* scn = reinterpret_cast<float*>(S.dpart);
+  pz_offsets_scan<NW>(S.part, scn, P.pz_c64, wave, lane);
   if (tid == (128 % NT)) {   // a lane of wave 2: tailstats -> (mean, sigma, tau)
     float tail_mean = 0.f, tail_sigma = 0.f, tail_tau = 0.f;
     if (S.sl->isum[IS_TAILBAD] == 0) {
@@ -417,19 +472,8 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
     S.outv[C_tail_tau] = tail_tau; S.outv[C_tail_mean] = tail_mean; S.outv[C_tail_sigma] = tail_sigma;
   }
   // InvCRFilter: y = x + c*cumsum(x)  (dsp_icpc.jl:119-120); x becomes y
-  {
-    double off[R];
-    wave_row_offsets(S.part, off, nullptr);
-    const f2 c2 = splat(P.pz_c);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float coff = (float)(P.pz_c64 * (off[r] + (double)(inc[r] - tot[r])));
-      const float r1 = x[r].x + x[r].y, r2 = r1 + x[r].z, r3 = r2 + x[r].w;   // running sums inside the quad
-      const f2 cf = splat(coff);
-      x[r].xy = fma2(c2, mk2(x[r].x, r1), x[r].xy + cf);
-      x[r].zw = fma2(c2, mk2(r2, r3), x[r].zw + cf);
-    }
-  }
+  __syncthreads();
+  pz_apply<NW>(x, inc, tot, scn, P.pz_c, wave);
   auto& y = x;
   STAMP(4); DSTOP(4);
 
@@ -665,20 +709,9 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       S.wsum[(W_PZ + 0) * NW + wave] = s1; S.wsum[(W_PZ + 1) * NW + wave] = s2; S.wsum[(W_PZ + 2) * NW + wave] = sx;
     }
     __syncthreads();   // also: every LS read of the SG output in B is done
-    double off[R], tot_all;
-    wave_row_offsets(pb, off, &tot_all);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      // T of the quad = (double offset) + (running sum inside the quad), split so that the per-sample work is float:
-      // hi = float(offset), lo = float(offset - hi), T[e] = hi + (lo + local[e]) — one rounding at the magnitude of T
-      const double o = off[r] + (double)(tin[r] - tot[r]);
-      const float hi = (float)o, lo = (float)(o - (double)hi);
-      const float l1 = y[r].x, l2 = l1 + y[r].y, l3 = l2 + y[r].z;
-      const f2 h2 = splat(hi), lo2 = splat(lo);
-      const f2 ta = h2 + (lo2 + mk2(0.f, l1)), tb = h2 + (lo2 + mk2(l2, l3));
-      *reinterpret_cast<f4*>(&S.B[4 * (tid + NT * r)]) = (f4){ta.x, ta.y, tb.x, tb.y};
-    }
-    if (tid == 0) S.B[Lp] = (float)tot_all;   // T[L]
+    t_offsets_scan<NW>(pb, scn + R * NW, &S.B[Lp], wave, lane);   // wave 0; T[L] -> B[Lp]
+    __syncthreads();
+    t_rows_store<NT>(y, tin, tot, scn + R * NW, S.B, tid, wave);
   }
   __syncthreads();
   STAMP(9); DSTOP(9);
@@ -1265,11 +1298,13 @@ pz_trap_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* B = reinterpret_cast<float*>(smem_raw);           // [Lp + 64] T, + 2 NT floats of slack: the lanes of the row pair that
   float* part = B + Lp + 64 + 2 * NT;                      // holds the end of the output range read past T (masked)   [2][R*NW]
-  float* wred = part + 2 * R * NW;                         // [2][NW]: s1 partials, trapezoid maxima
+  float* scn = part + 2 * R * NW;                          // [3][R*NW]: what wave 0 makes of the wave-row totals (row_prefix_f64)
+  float* wred = scn + 3 * R * NW;                          // [2][NW]: s1 partials, trapezoid maxima
   const float* w = wf + (size_t)blockIdx.x * (size_t)L;
   f4 x[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
+  asm volatile("; LDSP_PHASE 1");
   const float pv_bl = w[P.bl.from];
   const uint32_t cls_bl = P.rowcls[0][wave];
   {   // baseline sum: the s1 chain of icpc_lean_kernel's phase 1
@@ -1290,6 +1325,7 @@ pz_trap_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp
     LDSP_DPP_GROUP1("v_add_f32_dpp", s1);
     if (lane == 63) wred[wave] = s1;
   }
+  asm volatile("; LDSP_PHASE 2");
   __syncthreads();
   float s = 0.f;
 #pragma unroll
@@ -1308,28 +1344,11 @@ pz_trap_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp
     if (lane == 63) *reinterpret_cast<f4*>(&part[4 * wave]) = (f4){inc[0], inc[1], inc[2], inc[3]};
   }
   __syncthreads();
-  auto wave_row_offsets = [&](const float* pp, double (&off)[R], double* total) {
-    const int jr = lane / NW, jw = lane - jr * NW;
-    const double pvv = (lane < R * NW) ? (double)pp[4 * jw + jr] : 0.0;
-    const double pinc = wave_incl_scan_sum_f64(pvv);
-    const double pexc = pinc - pvv;
-#pragma unroll
-    for (int r = 0; r < R; ++r) off[r] = readlane_d(pexc, r * NW + wave);
-    if (total) *total = readlane_d(pinc, R * NW - 1);
-  };
-  {
-    double off[R];
-    wave_row_offsets(part, off, nullptr);
-    const f2 c2 = splat(P.pz_c);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float coff = (float)(P.pz_c64 * (off[r] + (double)(inc[r] - tot[r])));
-      const float r1 = x[r].x + x[r].y, r2 = r1 + x[r].z, r3 = r2 + x[r].w;
-      const f2 cf = splat(coff);
-      x[r].xy = fma2(c2, mk2(x[r].x, r1), x[r].xy + cf);
-      x[r].zw = fma2(c2, mk2(r2, r3), x[r].zw + cf);
-    }
-  }
+  asm volatile("; LDSP_PHASE 3");
+  pz_offsets_scan<NW>(part, scn, P.pz_c64, wave, lane);
+  __syncthreads();
+  pz_apply<NW>(x, inc, tot, scn, P.pz_c, wave);
+  asm volatile("; LDSP_PHASE 4");
   auto& y = x;
   {
     float tin[R];
@@ -1339,21 +1358,13 @@ pz_trap_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp
     float* pb = part + R * NW;
     if (lane == 63) *reinterpret_cast<f4*>(&pb[4 * wave]) = (f4){tin[0], tin[1], tin[2], tin[3]};
     __syncthreads();
-    double off[R], tot_all;
-    wave_row_offsets(pb, off, &tot_all);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const double o = off[r] + (double)(tin[r] - tot[r]);
-      const float hi = (float)o, lo = (float)(o - (double)hi);
-      const float l1 = y[r].x, l2 = l1 + y[r].y, l3 = l2 + y[r].z;
-      const f2 h2 = splat(hi), lo2 = splat(lo);
-      const f2 ta = h2 + (lo2 + mk2(0.f, l1)), tb = h2 + (lo2 + mk2(l2, l3));
-      *reinterpret_cast<f4*>(&B[4 * (tid + NT * r)]) = (f4){ta.x, ta.y, tb.x, tb.y};
-    }
-    if (tid == 0) B[Lp] = (float)tot_all;
+    t_offsets_scan<NW>(pb, scn + R * NW, &B[Lp], wave, lane);
+    __syncthreads();
+    t_rows_store<NT>(y, tin, tot, scn + R * NW, B, tid, wave);
     if (tid >= 1 && tid < 64) B[Lp + tid] = 0.f;
   }
   __syncthreads();
+  asm volatile("; LDSP_PHASE 5");
   float mx0 = -INFINITY;
   {
     const TrapDev f0 = P.fixed[0];
@@ -1362,16 +1373,45 @@ pz_trap_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp
     const f2 rr0 = splat(f0.rr);
     const int n0 = L - f0.flen + 1;
     auto rd2 = [&](const float* p, int m) { return mk2(p[NT * m], p[NT * (m + 1)]); };
-#pragma unroll
-    for (int m = 0; m < SP; m += 2) {
-      if (NT * m >= n0) continue;
+    // np full row pairs, then (maybe) the pair that holds the end of the output range: a jump into a run of straight-line
+    // pairs instead of two range tests per pair (the row offsets stay immediates)
+    auto pair = [&](auto mtag, bool whole) {
+      constexpr int m = decltype(mtag)::value;
       const f2 Tk = rd2(tb, m), a0 = rd2(f0a, m), b0 = rd2(f0b, m), c0_ = rd2(f0c, m);
       const f2 o0 = fma2(c0_ - b0, rr0, Tk - a0);
-      if (NT * (m + 2) <= n0) mx0 = vmax3(mx0, o0.x, o0.y);
+      if (whole) mx0 = vmax3(mx0, o0.x, o0.y);
       else mx0 = vmax3(mx0, tid + NT * m < n0 ? o0.x : -INFINITY, tid + NT * (m + 1) < n0 ? o0.y : -INFINITY);
+    };
+    static_assert(SP == 16, "eight row pairs");
+#define LDSP_PAIR(k) std::integral_constant<int, 2 * (k)>{}
+    const int np = n0 / (2 * NT);   // pairs wholly inside the output range (block-uniform)
+    switch (np) {
+      case 8: pair(LDSP_PAIR(7), true); [[fallthrough]];
+      case 7: pair(LDSP_PAIR(6), true); [[fallthrough]];
+      case 6: pair(LDSP_PAIR(5), true); [[fallthrough]];
+      case 5: pair(LDSP_PAIR(4), true); [[fallthrough]];
+      case 4: pair(LDSP_PAIR(3), true); [[fallthrough]];
+      case 3: pair(LDSP_PAIR(2), true); [[fallthrough]];
+      case 2: pair(LDSP_PAIR(1), true); [[fallthrough]];
+      case 1: pair(LDSP_PAIR(0), true); [[fallthrough]];
+      default: break;
     }
+    if (n0 > 2 * NT * np) {
+      switch (np) {
+        case 0: pair(LDSP_PAIR(0), false); break;
+        case 1: pair(LDSP_PAIR(1), false); break;
+        case 2: pair(LDSP_PAIR(2), false); break;
+        case 3: pair(LDSP_PAIR(3), false); break;
+        case 4: pair(LDSP_PAIR(4), false); break;
+        case 5: pair(LDSP_PAIR(5), false); break;
+        case 6: pair(LDSP_PAIR(6), false); break;
+        default: pair(LDSP_PAIR(7), false); break;
+      }
+    }
+#undef LDSP_PAIR
     mx0 *= f0.inv1;
   }
+  asm volatile("; LDSP_PHASE 6");
   LDSP_DPP_GROUP1("v_max_f32_dpp", mx0);
   if (lane == 63) wred[NW + wave] = mx0;
   __syncthreads();
@@ -1386,7 +1426,7 @@ pz_trap_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp
 template <int NT>
 static hipError_t launch_pz_t(const float* wf, int64_t n, const IcpcDev* dP, float* a, float* b, hipStream_t st) {
   constexpr int NW = NT / 64;
-  const size_t smem = (size_t)(NT * SP + 64 + 2 * NT + 2 * R * NW + 2 * NW) * 4 + 16;
+  const size_t smem = (size_t)(NT * SP + 64 + 2 * NT + 5 * R * NW + 2 * NW) * 4 + 16;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pz_trap_lean_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((pz_trap_lean_kernel<NT>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, a, b);
