@@ -258,6 +258,10 @@ typedef struct {
 } ldsp_icpc_opts;
 int ldsp_icpc_run_opts(ldsp_ctx* ctx, const float* wf, int64_t n, const ldsp_icpc_params* p,
                        const ldsp_icpc_opts* opts, const ldsp_icpc_out* out);
+/* Host-only: runs the complete lowering of a parameter block (the checks of the reference's window / filter
+ * arguments, filter constants and taps, launch geometry) and returns what ldsp_icpc_run would return for it before
+ * touching the device.  Needs no context and no GPU (config validation on a login node; sanitizer runs of the host code). */
+int ldsp_icpc_check_params(const ldsp_icpc_params* p);
 
 /* ---- "next" row 1: trapezoid filter-optimisation grid scans -----------
  * dsp_trap_rt_optimization (src/dsp_filter_optimization.jl:102-133: pick-off at a fixed

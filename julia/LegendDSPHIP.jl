@@ -217,6 +217,7 @@ function last_kernel_ms(c::LdspCtx)
     check(ccall((:ldsp_ctx_last_kernel_ms, libldsp), Cint, (Ptr{Cvoid}, Ptr{Cfloat}), c.h, r))
     r[]
 end
+check_params(p::LdspIcpcParams) = check(ccall((:ldsp_icpc_check_params, libldsp), Cint, (Ref{LdspIcpcParams},), p))
 last_kernel_name(c::LdspCtx) = unsafe_string(ccall((:ldsp_ctx_last_kernel_name, libldsp), Cstring, (Ptr{Cvoid},), c.h))
 function last_stage_ms(c::LdspCtx, stage::Integer)
     r = Ref{Cfloat}(0)

@@ -55,17 +55,6 @@ __device__ __forceinline__ float hsum(f2 v) { return v.x + v.y; }
 // keeps a value where it is computed: hipcc otherwise sinks the arithmetic of an accumulator to its next use (the following
 // phase) and the loads feeding it stay live across a barrier — in registers that are not there
 __device__ __forceinline__ void pin(f2& v) { asm volatile("" : "+v"(v)); }
-// A wave's ballots of 16 rows are collected in ONE register: v_writelane deposits the two halves of ballot `slot` in lanes
-// 2*slot and 2*slot+1 (+32 for a second mask); the words then go to LDS with a single ds_write_b32 of 32 (64) lanes
-// instead of a compare, a branch, two moves and a store per ballot.
-// (ballots a, b -> lanes lane0 .. lane0+3; the s_nop separates the v_cmp that wrote the SGPRs from their first read here —
-// hipcc does not see hazards of instructions inside an asm statement)
-__device__ __forceinline__ void put_ballots(uint32_t& acc, unsigned long long a, unsigned long long b, int lane0) {
-  asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %5\n\tv_writelane_b32 %0, %2, %6\n\tv_writelane_b32 %0, %3, %7\n\tv_writelane_b32 %0, %4, %8"
-               : "+v"(acc)
-               : "s"((uint32_t)a), "s"((uint32_t)(a >> 32)), "s"((uint32_t)b), "s"((uint32_t)(b >> 32)), "i"(lane0), "i"(lane0 + 1), "i"(lane0 + 2),
-                 "i"(lane0 + 3));
-}
 // arg-max over the wave, value first: the wave maximum of v (DPP chain, lane 63), then the smallest index among the lanes
 // that hold it (findmax: first occurrence).  Both results are valid in lane 63.
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {

@@ -102,7 +102,7 @@ int ldsp_ctx_destroy(ldsp_ctx* c) {
   if (!c) return LDSP_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_aux); (void)hipFree(c->d_coef); (void)hipFree(c->d_grid); (void)hipFree(c->d_fir_grid); (void)hipFree(c->d_sg_grid);
+  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_aux); (void)hipFree(c->d_coef); (void)hipFree(c->d_grid); (void)hipFree(c->d_fir_grid); (void)hipFree(c->d_sg_grid); (void)hipFree(c->d_sipm);
   (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); (void)hipEventDestroy(c->evm);
   (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -215,7 +215,9 @@ static TrapDev make_trap(const ldsp_trap& t) {
   d.rr = (float)((double)t.navg / (double)t.navg2); d.navg = (float)t.navg;
   return d;
 }
-static bool trap_ok(const ldsp_trap& t, int L) { return t.navg >= 1 && t.navg2 >= 1 && t.ngap >= 0 && t.navg + t.ngap + t.navg2 <= L; }
+static bool trap_ok(const ldsp_trap& t, int L) {   // (64-bit sum: the fields are whatever the caller's struct held)
+  return t.navg >= 1 && t.navg2 >= 1 && t.ngap >= 0 && (int64_t)t.navg + (int64_t)t.ngap + (int64_t)t.navg2 <= (int64_t)L;
+}
 
 static bool make_est(const ldsp_dni& e, EstDev& d) {
   if (e.npts < 1 || e.npts > LDSP_MAX_EST_PTS || e.degree < 0 || e.degree > LDSP_MAX_EST_DEG || e.degree >= e.npts) return false;
@@ -414,6 +416,19 @@ extern "C" {
 
 int ldsp_icpc_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_params* p, const ldsp_icpc_out* out) {
   return ldsp_icpc_run_opts(c, wf, n, p, nullptr, out);
+}
+
+// the whole host-side lowering of a parameter block (window / filter checks, filter constants and taps, launch geometry) without
+// a device: what ldsp_icpc_run would reject, it rejects with the same code and message
+int ldsp_icpc_check_params(const ldsp_icpc_params* p) {
+  if (!p) return fail(LDSP_ERR_INVALID_ARG, "ldsp_icpc_check_params: NULL argument");
+  std::vector<float> hc, hz;
+  IcpcDev d;
+  for (int direct = 0; direct < 2; ++direct) {
+    const int rc = lower_icpc_dev(*p, direct, 0, d, hc, hz);
+    if (rc) return rc;
+  }
+  return LDSP_OK;
 }
 
 int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_params* p, const ldsp_icpc_opts* opts,

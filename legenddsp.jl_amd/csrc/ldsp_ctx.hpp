@@ -1,5 +1,6 @@
 // ldsp_ctx.hpp — internals shared by the translation units that implement the C ABI.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
@@ -31,6 +32,8 @@ struct ldsp_ctx {
   float* d_fir_grid = nullptr;   // [fir_grid_cap] taps of ldsp_fir_grid_run (grow-only)
   size_t fir_grid_cap = 0;
   void* d_sg_grid = nullptr;  // SgGridDev of ldsp_sg_grid_run
+  void* d_sipm = nullptr;     // SipmDev of ldsp_sipm_run (k_sipm_s4 reads it through a pointer); re-uploaded when it changes
+  std::vector<unsigned char> sipm_last;
   void* d_grid = nullptr;   // TrapGridDev of ldsp_trap_grid_run (allocated on first use)
   float* d_coef = nullptr;  // [LDSP_MAX_FIR_TAPS] staging for functor coefficients / small tables
   int cusp_direct = 0;

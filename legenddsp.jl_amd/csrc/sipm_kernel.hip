@@ -32,7 +32,27 @@ struct SipmDev {
   int32_t trap_mintot, trap_maxtot;
   float trap_min_thr, trap_max_thr, trap_nsigma, trap_min_dc, trap_max_dc, trap_nsigma_dc;
   int32_t dbg_stop;  // profiling aid: return after stage k (tools/gpu_time_sipm.py)
+  long long* dbg_stamps;   // diagnostic build (-DLDSP_STAMPS, tools/dev_build_sipm.sh): s_memtime per wave at every SSTAMP
 };
+
+// SSTAMP(): the wave's next time stamp (slot = a per-wave counter in LDS) -> dbg_stamps[(block*16 + wave)*64 + slot]; compiled
+// in only with -DLDSP_STAMPS (tools/stamp_map_sipm.py reads the timeline)
+#ifdef LDSP_STAMPS
+__device__ __forceinline__ void s4_stamp(long long* st, bool init = false) {
+  __shared__ int wcnt[16];
+  if (init) { if (threadIdx.x < 16) wcnt[threadIdx.x] = 0; __syncthreads(); }
+  if (st && (threadIdx.x & 63) == 0 && blockIdx.x < 1024) {
+    const int w = threadIdx.x >> 6, k = wcnt[w];
+    wcnt[w] = k + 1;
+    if (k < 64) st[((size_t)blockIdx.x * 16 + w) * 64 + k] = (long long)__builtin_amdgcn_s_memtime();
+  }
+}
+#define SSTAMP_INIT(P) ::ldsp::sipm::s4_stamp((P).dbg_stamps, true)
+#define SSTAMP(P) ::ldsp::sipm::s4_stamp((P).dbg_stamps)
+#else
+#define SSTAMP_INIT(P) do { } while (0)
+#define SSTAMP(P) do { } while (0)
+#endif
 
 enum { S_t_max, S_t_min, S_t_max_lar, S_t_min_lar, S_e_max, S_e_min, S_e_max_lar, S_e_min_lar,
        S_blmean, S_blsigma, S_blslope, S_bloffset, S_wfmean, S_wfsigma, S_wfslope, S_wfoffset,
@@ -194,7 +214,7 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
 #include "sipm_s4.inc"
 
 template <int NT, int R, bool FULL>
-static hipError_t launch_s4(const float* wf, int64_t n, const SipmDev& d, const SipmOutDev& od, hipStream_t st) {
+static hipError_t launch_s4(const float* wf, int64_t n, const SipmDev* d, const SipmOutDev& od, hipStream_t st) {
   const size_t bytes = S4Lds<NT, R>::bytes();
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sipm_s4<NT, R, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
@@ -235,6 +255,7 @@ extern "C" int ldsp_sipm_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp
   d.trap_mintot = p->trap_mintot; d.trap_maxtot = p->trap_maxtot;
   d.trap_min_thr = (float)p->trap_min_thr; d.trap_max_thr = (float)p->trap_max_thr; d.trap_nsigma = (float)p->trap_nsigma;
   d.dbg_stop = c->dbg_stop;
+  d.dbg_stamps = c->dbg_stamps;
   d.trap_min_dc = (float)p->trap_min_dc_thr; d.trap_max_dc = (float)p->trap_max_dc_thr; d.trap_nsigma_dc = (float)p->trap_nsigma_dc;
   sipm::SipmOutDev od;
   static_assert(sizeof(ldsp_sipm_out) == sizeof(void*) * sipm::S_NCOLS + 4 * sizeof(ldsp_trig_out), "ldsp_sipm_out layout");
@@ -252,7 +273,19 @@ extern "C" int ldsp_sipm_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp
   bool launched = false;
   if (s4_ok) {
     // smallest tile that holds the trace: 32 samples per thread, 64 .. 512 threads
-#define LDSP_S4(N) (L == 32 * N ? sipm::launch_s4<N, 8, true>(wf, n, d, od, c->stream) : sipm::launch_s4<N, 8, false>(wf, n, d, od, c->stream))
+    // the parameter block travels through device memory (scalar loads where a value is needed instead of ~60 SGPRs held for
+    // the whole kernel); uploaded when it differs from the last call's
+    if (!c->d_sipm) HIP_TRY(hipMalloc(&c->d_sipm, sizeof(sipm::SipmDev)));
+    if (c->sipm_last.size() != sizeof d || memcmp(c->sipm_last.data(), &d, sizeof d)) {
+      HIP_TRY(hipMemcpyAsync(c->d_sipm, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));   // d dies at return
+      c->sipm_last.assign(reinterpret_cast<const unsigned char*>(&d), reinterpret_cast<const unsigned char*>(&d) + sizeof d);
+    }
+    const sipm::SipmDev* dd = reinterpret_cast<const sipm::SipmDev*>(c->d_sipm);
+    // FULL: the trace fills the tile AND the filters shorten it by at most one lane-strided row (N samples), so that only the
+    // last registers of a thread can lie behind the end of a filtered signal (s4_valid)
+    const bool tail_ok = (p->sg_npts - 1) + (flen - 1) <= 64;
+#define LDSP_S4(N) (L == 32 * N && tail_ok ? sipm::launch_s4<N, 8, true>(wf, n, dd, od, c->stream) : sipm::launch_s4<N, 8, false>(wf, n, dd, od, c->stream))
     launched = true;
     if (L <= 2048) e = LDSP_S4(64);
     else if (L <= 4096) e = LDSP_S4(128);
