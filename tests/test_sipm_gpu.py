@@ -44,6 +44,26 @@ def test_sipm_matches_oracle(orc):
     assert bad <= n // 50, f"{bad} traces differ (threshold-decision flips are rare, not {bad})"
 
 
+def test_sipm_same_discharge_bounds_for_both_pipelines(orc):
+    """min/max_dc_threshold equal in the sg and trap blocks: the kernel computes the discharge threshold once (block-uniform
+    shortcut in sipm_s4.inc) — threshold_DC_trap and the DC_trap triggers must still be what the oracle computes separately."""
+    import copy
+    n, L = 128, 16384
+    cfg = copy.deepcopy(dict(ldsp.reference_test_sipm_config()))
+    for k in ("min_dc_threshold", "max_dc_threshold"):
+        cfg["filters"]["trap"][k] = cfg["filters"]["sg"][k]
+    p = ldsp.lower_sipm(cfg, {"sg": {"wl": 200 * ldsp.ns}}, L, 0.0, 16.0)
+    assert p.sg_min_dc_thr == p.trap_min_dc_thr and p.sg_max_dc_thr == p.trap_max_dc_thr
+    wf = ldsp.synth.sipm_batch(n, L, device="cuda", seed=21)
+    wf[:32] -= ldsp.synth.sipm_batch(32, L, device="cuda", seed=22, noise=0.0, mean_pulses=2.0) * 3.0     # discharges
+    sc, trig = ldsp.sipm_run(wf, p)
+    torch.cuda.synchronize()
+    ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=16)
+    cols = ldsp._abi.SIPM_SCALAR_COLS
+    assert torch.equal(sc[cols.index("threshold_DC")], sc[cols.index("threshold_DC_trap")])
+    assert _compare(sc, trig, ora, n) <= n // 50
+
+
 def test_sipm_reference_fixture_properties():
     """test/test_dsp_sipm.jl:70-109: 10 identical noiseless 6250-sample pulses (L % 4 != 0)."""
     cfg = ldsp.reference_test_sipm_config()
