@@ -45,13 +45,11 @@ int ldsp_fail(int code, const char* fmt, ...) {
 }
 #define fail ldsp_fail
 
-int ldsp_check_batch(ldsp_ctx* c, const void* x, int64_t n, int32_t L, const char* who) {
+int ldsp_check_batch_impl(ldsp_ctx* c, const void* x, int64_t n, int32_t L, const char* who) {
   if (!c) return fail(LDSP_ERR_INVALID_ARG, "%s: ctx is NULL", who);
   if (n < 0 || n > 0x7fffffffLL) return fail(LDSP_ERR_INVALID_ARG, "%s: n = %lld out of range", who, (long long)n);
   if (L < 1 || L > LDSP_MAX_L) return fail(LDSP_ERR_UNSUPPORTED, "%s: trace length %d outside [1, %d]", who, L, LDSP_MAX_L);
   if (n > 0 && !x) return fail(LDSP_ERR_INVALID_ARG, "%s: waveform pointer is NULL", who);
-  hipError_t e = hipSetDevice(c->device);
-  if (e != hipSuccess) return fail(LDSP_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
   // an error another library left behind on this thread (e.g. a failed pointer-attribute probe of the host program) must
   // not be reported as the failure of the launch below, which reads hipGetLastError() after it
   (void)hipGetLastError();
@@ -76,15 +74,8 @@ int64_t ldsp_abi_sizeof(int which) {
 
 const char* ldsp_last_error_string(void) { return g_err.c_str(); }
 
-int ldsp_ctx_create(int device, ldsp_ctx** out) {
-  if (!out) return fail(LDSP_ERR_INVALID_ARG, "ldsp_ctx_create: out is NULL");
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (device < 0 || device >= ndev) return fail(LDSP_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
-  HIP_TRY(hipSetDevice(device));
-  ldsp_ctx* c = new (std::nothrow) ldsp_ctx();
-  if (!c) return fail(LDSP_ERR_NOMEM, "out of host memory");
-  c->device = device;
+int ldsp_ctx_destroy(ldsp_ctx* c);
+static int ctx_build(ldsp_ctx* c) {
   HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   HIP_TRY(hipMalloc(&c->d_icpc, sizeof(IcpcDev)));
@@ -94,17 +85,39 @@ int ldsp_ctx_create(int device, ldsp_ctx** out) {
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipEventCreate(&c->evm));
+  return LDSP_OK;
+}
+
+int ldsp_ctx_create(int device, ldsp_ctx** out) {
+  if (!out) return fail(LDSP_ERR_INVALID_ARG, "ldsp_ctx_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(LDSP_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
+  ldsp_device_guard guard(device);
+  ldsp_ctx* c = new (std::nothrow) ldsp_ctx();
+  if (!c) return fail(LDSP_ERR_NOMEM, "out of host memory");
+  c->device = device;
+  const int rc = ctx_build(c);
+  if (rc) {   // a half-built context is released (the error string of the failing call is kept)
+    const std::string keep = g_err;
+    (void)ldsp_ctx_destroy(c);
+    g_err = keep;
+    return rc;
+  }
   *out = c;
   return LDSP_OK;
 }
 
 int ldsp_ctx_destroy(ldsp_ctx* c) {
   if (!c) return LDSP_OK;
-  (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  ldsp_device_guard guard(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_aux); (void)hipFree(c->d_coef); (void)hipFree(c->d_grid); (void)hipFree(c->d_fir_grid); (void)hipFree(c->d_sg_grid); (void)hipFree(c->d_sipm);
-  (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); (void)hipEventDestroy(c->evm);
-  (void)hipStreamDestroy(c->own_stream);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->evm) (void)hipEventDestroy(c->evm);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return LDSP_OK;
 }
@@ -440,7 +453,7 @@ int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_
   if (n < 0 || n > 0x7fffffffLL) return fail(LDSP_ERR_INVALID_ARG, "n = %lld out of range", (long long)n);
   if (n == 0) return LDSP_OK;
   if (!wf) return fail(LDSP_ERR_INVALID_ARG, "waveform pointer is NULL");
-  HIP_TRY(hipSetDevice(c->device));
+  ldsp_device_guard guard(c->device);
   int rc = prepare_icpc(c, p);
   if (rc) return rc;
   IcpcOutDev od;
@@ -481,7 +494,7 @@ int ldsp_icpc_pz_trap_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_ic
   if (n < 0 || n > 0x7fffffffLL) return fail(LDSP_ERR_INVALID_ARG, "n = %lld out of range", (long long)n);
   if (n == 0) return LDSP_OK;
   if (!wf) return fail(LDSP_ERR_INVALID_ARG, "waveform pointer is NULL");
-  HIP_TRY(hipSetDevice(c->device));
+  ldsp_device_guard guard(c->device);
   int rc = prepare_icpc(c, p);
   if (rc) return rc;
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -526,7 +539,6 @@ int ldsp_trap_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapg
     d.trap[g] = make_trap(traps[g]);
     d.offs[g] = offsets ? (float)(offsets[g] / p->dt) : 0.f;
   }
-  HIP_TRY(hipSetDevice(c->device));
   if (!c->d_grid) HIP_TRY(hipMalloc(&c->d_grid, sizeof(TrapGridDev) > sizeof(FirGridDev) ? sizeof(TrapGridDev) : sizeof(FirGridDev)));
   HIP_TRY(hipMemcpyAsync(c->d_grid, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));   // the staging block is reused by the next call
@@ -565,7 +577,6 @@ int ldsp_fir_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgr
   d.same_offs = 1;
   for (int g = 1; g < G; ++g) d.same_offs &= (d.offs[g] == d.offs[0]);
   if (c->fir_grid_per_point) d.same_offs = 0;
-  HIP_TRY(hipSetDevice(c->device));
   const size_t ntap = (size_t)G * (size_t)Lf;
   if (ntap > c->fir_grid_cap) {   // grow-only tap buffer
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -623,7 +634,6 @@ int ldsp_sg_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgri
     d.np[g] = np; d.from[g] = from[g]; d.until[g] = until[g];
     for (int i = 0; i < np; ++i) d.c[g][i] = (float)cc[i];
   }
-  HIP_TRY(hipSetDevice(c->device));
   if (!c->d_sg_grid) HIP_TRY(hipMalloc(&c->d_sg_grid, sizeof(SgGridDev)));
   HIP_TRY(hipMemcpyAsync(c->d_sg_grid, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -15,6 +15,22 @@ int ldsp_fail(int code, const char* fmt, ...);
     if (_e != hipSuccess) return ldsp_fail(LDSP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
   } while (0)
 
+// Makes `dev` the calling thread's current HIP device for the lifetime of the object and restores the caller's device
+// afterwards (torch reads the current device through hipGetDevice: an entry point that left ITS device current would move
+// later device='cuda' allocations of a multi-GPU process to the wrong GPU).  dev < 0: no-op.
+struct ldsp_device_guard {
+  int prev = -1;
+  explicit ldsp_device_guard(int dev) {
+    if (dev < 0) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != dev) { prev = cur; (void)hipSetDevice(dev); }
+    else if (cur < 0) (void)hipSetDevice(dev);
+  }
+  ~ldsp_device_guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  ldsp_device_guard(const ldsp_device_guard&) = delete;
+  ldsp_device_guard& operator=(const ldsp_device_guard&) = delete;
+};
+
 struct ldsp_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -54,3 +70,8 @@ struct ldsp_ctx {
 
 // common argument checks of the per-trace entry points
 int ldsp_check_batch(ldsp_ctx* c, const void* x, int64_t n, int32_t L, const char* who);
+
+// Argument checks common to the batch entry points, then the context's device made current for the rest of the CALLER's scope
+// (restored at its exit).  Used as a statement:  int rc = ldsp_check_batch(c, x, n, L, "name");
+int ldsp_check_batch_impl(ldsp_ctx* c, const void* x, int64_t n, int32_t L, const char* who);
+#define ldsp_check_batch(c, x, n, L, who) ldsp_check_batch_impl((c), (x), (n), (L), (who)); ldsp_device_guard ldsp_guard_((c) ? (c)->device : -1)
