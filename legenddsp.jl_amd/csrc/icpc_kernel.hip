@@ -116,6 +116,20 @@ struct Smem {
   }
 };
 
+// the same with a first leg of <= 3 samples summed from the samples themselves (as in sweep A: on the tail a difference of two
+// float prefix sums of 1e8 is good to a few counts only, the size of the t0 threshold)
+__device__ __forceinline__ float trap_at_y(const float* T, const float* y, int k, const TrapDev& t) {
+  const float a = T[k + t.flen] - T[k + t.n1 + t.g];
+  float b;
+  if (t.n1 <= 3) {
+    b = y[k];
+    if (t.n1 >= 2) b += y[k + 1];
+    if (t.n1 >= 3) b += y[k + 2];
+  } else {
+    b = T[k + t.n1] - T[k];
+  }
+  return a * t.inv2 - b * t.inv1;
+}
 __device__ __forceinline__ float trap_at(const float* T, int k, const TrapDev& t) {
   float a = T[k + t.flen] - T[k + t.n1 + t.g];
   float b = T[k + t.n1] - T[k];
@@ -1460,7 +1474,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
       } else {
         const bool inv = (q == 6);
         const TrapDev& t = (inv && !P.t0inv_same) ? P.t0inv : P.t0;
-        yl = trap_at(S.B1, p - 1, t); yh = trap_at(S.B1, p, t);
+        yl = trap_at_y(S.B1, S.B0, p - 1, t); yh = trap_at_y(S.B1, S.B0, p, t);
         if (inv) { yl = -yl; yh = -yh; }
         base = p - 1 + (t.flen - 1);  // trailing alignment (A1): back to input index space
       }

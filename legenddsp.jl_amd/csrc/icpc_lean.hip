@@ -82,6 +82,20 @@ __device__ __forceinline__ Pos pos_add(Pos p, float d) {
   p.fp += d - di;
   return pos_norm(p);
 }
+// the same with a first leg of <= 3 samples summed from the samples themselves (as in sweep A: on the tail a difference of two
+// float prefix sums of 1e8 is good to a few counts only, the size of the t0 threshold)
+__device__ __forceinline__ float trap_at_y(const float* T, const float* y, int k, const TrapDev& t) {
+  const float a = T[k + t.flen] - T[k + t.n1 + t.g];
+  float b;
+  if (t.n1 <= 3) {
+    b = y[k];
+    if (t.n1 >= 2) b += y[k + 1];
+    if (t.n1 >= 3) b += y[k + 2];
+  } else {
+    b = T[k + t.n1] - T[k];
+  }
+  return a * t.inv2 - b * t.inv1;
+}
 __device__ __forceinline__ float trap_at(const float* T, int k, const TrapDev& t) {
   const float a = T[k + t.flen] - T[k + t.n1 + t.g];
   const float b = T[k + t.n1] - T[k];
@@ -912,7 +926,7 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       if (q < 5) {
         yl = S.A[p - 1]; yh = S.A[p]; base = p - 1;
       } else {
-        yl = trap_at(S.B, p - 1, P.t0); yh = trap_at(S.B, p, P.t0);
+        yl = trap_at_y(S.B, S.A, p - 1, P.t0); yh = trap_at_y(S.B, S.A, p, P.t0);
         if (q == 6) { yl = -yl; yh = -yh; }
         base = p - 1 + (P.t0.flen - 1);   // trailing alignment (A1): back to input index space
       }
@@ -974,7 +988,9 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
         const Pos p1 = pos_add(base, d1), p2 = pos_add(base, d2);
         const int ips[3] = {base.ip, p1.ip, p2.ip};
         const float fps[3] = {base.fp, p1.fp, p2.fp};
-        const float res = qdrift_wave(P.int_est, S.estB + EST_TBL, S.A, L, ips, fps);
+        // scratch: the rows of the general threshold scan (M_FB..) — the crossings are done, the CUSP/ZAC stage clears the gap later
+        float* scr = (5 * NWORDS >= 1024) ? reinterpret_cast<float*>(S.bm + M_FB * NWORDS) + (is_lq ? 512 : 0) : nullptr;
+        const float res = qdrift_wave(P.int_est, S.estB + EST_TBL, S.A, L, ips, fps, scr);
         if (lane == 0) eslot[is_lq ? 2 : 1] = res;
       }
     }

@@ -30,7 +30,12 @@ __device__ __forceinline__ float dni_weight(const EstDev& E, const float* Bt, in
 
 // Y: the trace in LDS (nsig samples); Bt: the estimator's basis table in LDS; (ip[k], fp[k]): the three positions t, t + d1, t + d2
 // in samples.  Must be called by all 64 lanes of a wave.  NaN if the trace is shorter than the estimator window.
-__device__ __forceinline__ float qdrift_wave(const EstDev& E, const float* Bt, const float* Y, int nsig, const int (&ip)[3], const float (&fp)[3]) {
+// scratch: 512 floats of LDS this wave may use, or nullptr.  With it (and a span of <= 512 samples) every sample is read once:
+// a lane loads its <= 8 consecutive samples with independent reads, the prefix sums D(i) go to scratch and the window points
+// fetch theirs with one read — instead of a chain of ~20 dependent LDS round trips (the waves of the workgroup that have
+// nothing to do in this phase wait for this one).
+__device__ __forceinline__ float qdrift_wave(const EstDev& E, const float* Bt, const float* Y, int nsig, const int (&ip)[3], const float (&fp)[3],
+                                             float* scratch = nullptr) {
   if (nsig < E.npts) return NAN;   // (wave-uniform)
   const int lane = threadIdx.x & 63;
   int i0[3]; float u[3];
@@ -39,22 +44,47 @@ __device__ __forceinline__ float qdrift_wave(const EstDev& E, const float* Bt, c
   const int ref = min(i0[0], min(i0[1], i0[2]));
   const int span = max(i0[0], max(i0[1], i0[2])) + E.npts - 1 - ref;   // samples ref+1 .. ref+span
   const int ch = (span + 63) / 64;                                       // consecutive samples per lane
-  float loc = 0.f;
-  for (int j = 0; j < ch; ++j) { const int i = ref + 1 + lane * ch + j; if (i <= ref + span) loc += Y[i]; }
-  float incl = loc;
-  LDSP_DPP_GROUP1("v_add_f32_dpp", incl);
-  const float excl = incl - loc;   // sum of the chunks before this lane's
-  // lane l < npts: point l of each window in turn.  D(i) for i = ref + 1 + c*ch + j: the chunks before c + the first j+1 samples
-  // of chunk c (every lane takes part in the shuffle)
+  constexpr int CH = 8;
   float t = 0.f;
+  if (scratch && ch <= CH) {   // (wave-uniform)
+    float v[CH];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int i = (lane < E.npts) ? i0[k] + lane : ref;
-    const int o = max(i - ref - 1, 0), c = ch > 0 ? o / ch : 0, jj = o - c * ch;
-    float d = __shfl(excl, c);
-    for (int j = 0; j <= jj; ++j) d += Y[ref + 1 + c * ch + j];
-    if (i <= ref) d = 0.f;
-    if (lane < E.npts) t = fmaf(dni_weight(E, Bt, lane, u[k]) * ((k == 1) ? -2.f : 1.f), d, t);   // E1 - 2 E2 + E3
+    for (int j = 0; j < CH; ++j) {
+      const int i = ref + 1 + lane * ch + j;
+      v[j] = (j < ch && i <= ref + span) ? Y[i] : 0.f;
+    }
+#pragma unroll
+    for (int j = 1; j < CH; ++j) v[j] += v[j - 1];
+    float incl = v[CH - 1];
+    LDSP_DPP_GROUP1("v_add_f32_dpp", incl);
+    const float excl = incl - v[CH - 1];
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+      if (j < ch) scratch[lane * ch + j] = excl + v[j];   // D(ref + 1 + o) at scratch[o]
+    // (the wave's own LDS writes and reads are ordered)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = (lane < E.npts) ? i0[k] + lane : ref;
+      const float d = (i > ref) ? scratch[i - ref - 1] : 0.f;
+      if (lane < E.npts) t = fmaf(dni_weight(E, Bt, lane, u[k]) * ((k == 1) ? -2.f : 1.f), d, t);   // E1 - 2 E2 + E3
+    }
+  } else {
+    float loc = 0.f;
+    for (int j = 0; j < ch; ++j) { const int i = ref + 1 + lane * ch + j; if (i <= ref + span) loc += Y[i]; }
+    float incl = loc;
+    LDSP_DPP_GROUP1("v_add_f32_dpp", incl);
+    const float excl = incl - loc;   // sum of the chunks before this lane's
+    // lane l < npts: point l of each window in turn.  D(i) for i = ref + 1 + c*ch + j: the chunks before c + the first j+1
+    // samples of chunk c (every lane takes part in the shuffle)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = (lane < E.npts) ? i0[k] + lane : ref;
+      const int o = max(i - ref - 1, 0), c = ch > 0 ? o / ch : 0, jj = o - c * ch;
+      float d = __shfl(excl, c);
+      for (int j = 0; j <= jj; ++j) d += Y[ref + 1 + c * ch + j];
+      if (i <= ref) d = 0.f;
+      if (lane < E.npts) t = fmaf(dni_weight(E, Bt, lane, u[k]) * ((k == 1) ? -2.f : 1.f), d, t);   // E1 - 2 E2 + E3
+    }
   }
   LDSP_DPP_GROUP1("v_add_f32_dpp", t);
   return readlane_f(t, 63);

@@ -50,7 +50,12 @@ def _window(w, start, stop):
 
 
 def _per_trace(v, n, dev):
+    """a per-trace argument (threshold, time) as a device float32 [n]: a tensor of n elements, or a scalar for every trace"""
     if isinstance(v, torch.Tensor):
+        if v.numel() == 1:
+            return torch.full((n,), float(v), dtype=torch.float32, device=dev)
+        if v.shape != (n,):      # the kernel reads element i for trace i: anything else would read out of bounds
+            raise ValueError(f"per-trace argument has shape {tuple(v.shape)}, expected ({n},) or a scalar")
         return v.to(device=dev, dtype=torch.float32).contiguous()
     return torch.full((n,), float(v), dtype=torch.float32, device=dev)
 

@@ -65,3 +65,15 @@ def test_no_overflow_no_second_pass():
     groups = {"a": _group([1, 4, 0], 4)}
     out = resolve_overflow(groups, lambda rows, cap: (_ for _ in ()).throw(AssertionError("must not run")))
     assert "overflow" not in out["a"]
+
+
+def test_per_trace_argument_must_match_the_batch():
+    """A per-trace threshold / time tensor of the wrong length would make the kernel read out of bounds: refused on the host."""
+    from legenddsp_jl_amd.extractors import _per_trace
+    assert _per_trace(2.5, 4, "cpu").tolist() == [2.5] * 4
+    assert _per_trace(torch.tensor(1.5), 3, "cpu").tolist() == [1.5] * 3
+    assert _per_trace(torch.arange(4.0), 4, "cpu").tolist() == [0.0, 1.0, 2.0, 3.0]
+    with pytest.raises(ValueError):
+        _per_trace(torch.arange(5.0), 4, "cpu")
+    with pytest.raises(ValueError):
+        _per_trace(torch.zeros(4, 1), 4, "cpu")

@@ -19,13 +19,22 @@ ldsp.icpc_run(wf, params, ctx, out=out)          # warm-up without stamps
 ctx.set_option("dbg_stamps", buf.data_ptr())
 ldsp.icpc_run(wf, params, ctx, out=out)
 torch.cuda.synchronize()
+names = lean if "lean" in ctx.last_kernel_name() else generic
+print("kernel:", ctx.last_kernel_name())
 ctx.set_option("dbg_stamps", 0)
 s = buf.cpu().numpy()[:, :NW, :].astype(np.float64)     # [block, wave, slot]
-names = {0: "start", 1: "load + raw sums", 2: "bl reduce + barrier", 3: "blmean, saturation", 4: "shift, tail logs, cumsum scan",
-         5: "pz + y -> LDS + barrier", 6: "SG pass", 7: "SG reductions + barrier", 8: "wvf maxima, SG masks", 9: "T scan + T -> LDS + barrier",
-         10: "sweep A (7 masks)", 11: "sweep B (4 trapezoids)", 12: "sweep reductions + barrier", 13: "run scans + barrier",
-         14: "crossings", 15: "estimators + barrier", 16: "CZ: Dp (+barrier)", 17: "CZ: flat top + ZAC taps", 18: "CZ: d, causal scan + readback",
-         19: "CZ: anti-causal scan + readback", 20: "CZ: double cumsum + readback", 21: "CZ: finish", 22: "CZ: collect"}
+generic = {0: "start", 1: "load + raw sums", 2: "bl reduce + barrier", 3: "blmean, saturation", 4: "shift, tail logs, cumsum scan",
+           5: "pz + y -> LDS + barrier", 6: "SG pass", 7: "SG reductions + barrier", 8: "wvf maxima, SG masks", 9: "T scan + T -> LDS + barrier",
+           10: "sweep A (7 masks)", 11: "sweep B (4 trapezoids)", 12: "sweep reductions + barrier", 13: "run scans + barrier",
+           14: "crossings", 15: "estimators + barrier", 16: "CZ: Dp (+barrier)", 17: "CZ: flat top + ZAC taps", 18: "CZ: d, causal scan + readback",
+           19: "CZ: anti-causal scan + readback", 20: "CZ: double cumsum + readback", 21: "CZ: finish", 22: "CZ: collect"}
+lean = {0: "start", 1: "load, raw extremes, baseline sums", 2: "per-wave partials + barrier", 3: "blmean, shift, tail sums, cumsum scan + barrier",
+        4: "pz offsets (wave 0) + barrier, pole-zero", 5: "y -> LDS, wvf maxima + barrier", 6: "SG pass (S4, packed)", 7: "SG reductions",
+        8: "LS pass: sg50 crossing, in-trace mask", 9: "T scan (wave 0) + T -> LDS + barriers", 10: "sweep A (t0 masks)",
+        11: "sweep B (4 trapezoids)", 12: "sweep reductions + barrier", 13: "run scans on the masks + barrier",
+        14: "threshold confirmation, crossings", 15: "estimators (waves 0-2) + barrier", 16: "CZ: Dp, d (+barrier)",
+        17: "CZ: flat top + ZAC taps (summed by parts)", 18: "CZ: causal scan + readback", 19: "CZ: anti-causal scan + readback",
+        20: "CZ: double cumsum + readback", 21: "CZ: maxima, estimator points", 22: "CZ: collect"}
 ids = sorted(names)
 valid = (s[:, :, ids] > 0).all(axis=(1, 2))
 s = s[valid]
