@@ -46,7 +46,7 @@ ATOL = {
     "e_10410": 0.05, "e_535": 0.05, "e_313": 0.05, "e_10410_inv": 0.05, "e_313_inv": 0.1,
     "e_trap": 0.05, "e_cusp": 0.1, "e_zac": 0.1, "e_trap_max": 0.05, "e_cusp_max": 0.1, "e_zac_max": 0.1,
     # qdrift / lq: the integrator is taken relative to the first window point (csrc/qdrift.hpp); was 40 with float32 prefix sums
-    "qdrift": 3.0, "lq": 3.0, "a_sg": 5e-3, "a_60": 5e-3, "a_100": 5e-3, "a_raw": 5e-3,
+    "qdrift": 2.0, "lq": 2.0, "a_sg": 5e-3, "a_60": 5e-3, "a_100": 5e-3, "a_raw": 5e-3,
     "drift_time": 0.6, "inTrace_intersect": 0.6,
 }
 SIGMA_LEVEL = {"blsigma": "blmean", "tailsigma": "tailmean"}     # sigma column -> the level its samples are rounded at
