@@ -18,6 +18,8 @@ inherits the rounding of another quantity, that quantity's share (written next t
                           derivative has a plateau of (nearly) equal samples and the arg-max is decided by the last bit;
                           accepted when the value equals the parabola through ANOTHER sample of that plateau (needs the
                           trace: compare(..., wf=, params=, orc=))
+  inTrace_*               not compared on noise-free traces (blsigma <= 3e-6 * |blmean|: the threshold then sits on the rounding
+                          residue of the baseline and each side counts its own rounding)
   integer columns         exact; inTrace_n (a count of ~10..150 noise crossings of a threshold that is itself a float32
                           sigma) may differ by <= 3 on a fraction of rows <= max(FLIP_FRAC, 6e-3 * mean count):
                           at a noise sigma of 1 count the float32 rounding of the Savitzky-Golay output (2e-4) is 0.2 % of its
@@ -41,7 +43,7 @@ INT_COLS = _abi.ICPC_I32_COLS
 ATOL = {
     "blmean": 2e-3, "blsigma": 2e-4, "blslope": 1e-8, "bloffset": 2e-3,
     "tailmean": 0.05, "tailsigma": 5e-3, "tailslope": 2e-7, "tailoffset": 0.05,
-    "tail_tau": 50.0, "tail_mean": 2e-6, "tail_sigma": 5e-6,
+    "tail_tau": 50.0, "tail_mean": 2e-6, "tail_sigma": 1e-5,
     "e_max": 2e-3, "e_min": 2e-3,
     "e_10410": 0.05, "e_535": 0.05, "e_313": 0.05, "e_10410_inv": 0.05, "e_313_inv": 0.1,
     "e_trap": 0.05, "e_cusp": 0.1, "e_zac": 0.1, "e_trap_max": 0.05, "e_cusp_max": 0.1, "e_zac_max": 0.1,
@@ -111,7 +113,17 @@ def bad_mask(c, gpu, ora, wf=None, params=None, orc=None):
         if c == "a_raw" and bad.any() and wf is not None and params is not None and orc is not None:
             rows = np.nonzero(bad)[0]
             bad[rows[_a_raw_tie(rows, a[rows], ora, wf, params, orc)]] = False
+    if c in ("inTrace_n", "inTrace_intersect"):
+        # On a noise-free trace the pile-up threshold is n_sigma times the sigma of the ROUNDING residue of the baseline (1e-4 of a
+        # 1000-count level) and the crossings it counts are crossings of that residue: both sides count their own rounding.
+        bad &= ~noise_free(ora)
     return bad, err
+
+
+def noise_free(ora):
+    """rows whose baseline sigma is at the float32 rounding of its level (see bad_mask, inTrace columns)"""
+    blm, bls = np.abs(np.asarray(ora["blmean"], dtype=np.float64)), np.asarray(ora["blsigma"], dtype=np.float64)
+    return bls <= 3e-6 * blm + 1e-9
 
 
 def params_dt(params):
@@ -134,7 +146,7 @@ def compare(gpu: dict, ora: dict, verbose=False, wf=None, params=None, orc=None)
         frac = bad.sum() / max(n, 1)
         note = ""
         if c == "inTrace_n":      # small differences: a separate, count-dependent budget on the fraction of rows
-            soft_rows = (err > 0) & ~bad
+            soft_rows = (err > 0) & ~bad & ~noise_free(ora)
             allowed = max(FLIP_FRAC, 6e-3 * float(np.nanmean(b))) if n else FLIP_FRAC
             note = f"  (differ by <= {INTRACE_MAX_DIFF}: {int(soft_rows.sum())}/{n}, allowed {allowed:.3f}, mean count {float(np.nanmean(b)):.1f})"
             if soft_rows.sum() / max(n, 1) > allowed:
