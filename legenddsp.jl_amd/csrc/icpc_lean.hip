@@ -14,6 +14,7 @@
 // have at most M taps, the inverted t0 uses the same trapezoid and tx_mintot = 2 samples; every other configuration runs
 // icpc_kernel (option "icpc_generic" forces it: the comparator of tests/test_icpc_gpu.py).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include <stddef.h>
 #include "icpc_dev.hpp"
@@ -289,8 +290,8 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
   const IcpcDev& P = *Pp;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int Lf = P.cusp.Lf;
-  SM S(smem_raw, cz_pad_floats(Lf));
+  const int Lf_max = max(P.cusp.Lf, P.zac.Lf);   // (equal when the two filters share their geometry)
+  SM S(smem_raw, cz_pad_floats(Lf_max));
   const float* w = wf + (size_t)blockIdx.x * (size_t)L;
   // first sample of this wave's 256-sample row r, and how a window [from, until] meets that row (wave-uniform)
   auto wrow = [&](int r) { return 4 * (64 * wave + NT * r); };
@@ -968,16 +969,23 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       }
       if (lane == 0) eslot[0] = v;
       // windows of the CUSP / ZAC estimates (t50 + flt_length/2, dsp_icpc.jl:170,177) for the last phase
-      const int nout_cz = L - Lf + 1;
-      if (nout_cz >= P.sig_est.npts) {
-        Pos pc_ = pos_add(ptx1, P.cusp_pickoff), pz2 = pos_add(ptx1, P.zac_pickoff);
-        pc_.ip -= (Lf - 1); pz2.ip -= (Lf - 1);
-        int i0c, i0z; float uc, uz;
-        est_window(P.sig_est, pc_, nout_cz, &i0c, &uc);
-        est_window(P.sig_est, pz2, nout_cz, &i0z, &uz);
+      const int nout_c = L - P.cusp.Lf + 1, nout_z = L - P.zac.Lf + 1;
+      if (lane == 0) { S.misc[12] = 0.f; S.misc[13] = 0.f; }
+      if (nout_c >= P.sig_est.npts) {
+        Pos pc_ = pos_add(ptx1, P.cusp_pickoff);
+        pc_.ip -= (P.cusp.Lf - 1);
+        int i0c; float uc;
+        est_window(P.sig_est, pc_, nout_c, &i0c, &uc);
         // the level at the left edge of the pick-off window: the CUSP / ZAC stage runs on y - cpiv (see there)
-        if (lane == 0) { S.misc[8] = __int_as_float(i0c); S.misc[9] = uc; S.misc[10] = __int_as_float(i0z); S.misc[11] = uz; S.misc[12] = S.A[i0c]; }
-      } else if (lane == 0) S.misc[12] = 0.f;
+        if (lane == 0) { S.misc[8] = __int_as_float(i0c); S.misc[9] = uc; S.misc[12] = S.A[i0c]; }
+      }
+      if (nout_z >= P.sig_est.npts) {
+        Pos pz2 = pos_add(ptx1, P.zac_pickoff);
+        pz2.ip -= (P.zac.Lf - 1);
+        int i0z; float uz;
+        est_window(P.sig_est, pz2, nout_z, &i0z, &uz);
+        if (lane == 0) { S.misc[10] = __int_as_float(i0z); S.misc[11] = uz; S.misc[13] = S.A[i0z]; }
+      }
     }
     if (wave == 1 % NW || wave == 2 % NW) {
       const bool lq = (NW > 2) ? wave == 2 : false;
@@ -1009,9 +1017,12 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
   // w = sinh flanks + flat top (+ parabolas for ZAC) splits into a causal one-pole G, an anti-causal one-pole A, the prefix sum
   // Dp of d, and a double prefix sum of a sparse combination u of Dp; each is built in the S4 view and read back lane-strided,
   // two rows per step.
-  {
-    const CuspZacDev& Z = P.cusp;
-    const CuspZacDev& ZZ = P.zac;
+  // One pass evaluates the filters that share Z's geometry: both (WC, WZ: the usual case, ZAC = CUSP + parabola corrections), or one
+  // of them when the two were optimised separately (pars_filter): then CUSP first, y and T are put back, and ZAC follows with
+  // Z = ZZ = P.zac (its own flat top / last tap come out of the same statements with dwl = 0).
+  auto cz_pass = [&](auto wc_tag, auto wz_tag, const CuspZacDev& Z, const CuspZacDev& ZZ, const float cpiv) {
+    constexpr bool WC = decltype(wc_tag)::value, WZ = decltype(wz_tag)::value;
+    const int Lf = Z.Lf;
     const int nout = L - Lf + 1, lt = Z.lt, f1 = Z.f1, ltp = Z.ltp;
     const int pad = cz_pad_floats(Lf);
     for (int i = tid; i < pad; i += NT) S.B[i - pad] = 0.f;   // the gap (dead mask words) becomes Dp[i < 0] = 0
@@ -1025,7 +1036,6 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
     // y' = y - cpiv, cpiv = the level at the left edge of the pick-off window (any constant is exact mathematically:
     // out = out' + cpiv * hsum, hsum = the sum of the direct-form taps), which makes every trace look like a clean one.
     // y' is never materialised:  Dp' = Dp - eps*cpiv*i,  d' = d - eps*cpiv,  the taps on y[k] fold cpiv into their fma.
-    const float cpiv = S.misc[12];
     const float mec = -Z.eps * cpiv;
     // ---- Dp[i] = y[i] - y[0] + eps*T[i] -> B, in place of T (each thread converts its own quads)
     {
@@ -1068,6 +1078,7 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
         pin(ac[m / 2]); pin(dz[m / 2]);
         if ((m & 2) == 2) __builtin_amdgcn_sched_barrier(0);   // at most two pairs of rows of loads in flight (register pressure)
       }
+      if constexpr (WZ) {
       f2 u[SP / 2];
 #pragma unroll
       for (int m = 0; m < SP / 2; ++m) u[m] = splat(0.f);
@@ -1080,6 +1091,7 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       }
 #pragma unroll
       for (int m = 0; m < SP; m += 2) { S.A[tid + NT * m] = u[m / 2].x; S.A[tid + NT * (m + 1)] = u[m / 2].y; }   // own elements: race-free
+      }
     }
     STAMP(17); DSTOP(17);
     const float q1 = Z.qp1[1];
@@ -1153,6 +1165,7 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       }
     }
     STAMP(19); DSTOP(19);
+    if constexpr (WZ) {
     // ---- ZAC parabolas: PRF = cumsum(cumsum(u)) (S4; u was parked in A).  Two levels: inside a wave-row (256 samples) the
     // single and double running sums l1, l2 start from zero and stay in float; the state entering each wave-row, (C1, C2), is
     // carried in double:  c2[j] = C2 + (j+1)*C1 + l2[j],  C1' = C1 + l1[255],  C2' = C2 + 256*C1 + l2[255].
@@ -1208,6 +1221,7 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
 #pragma unroll
       for (int m = 0; m < SP; m += 2) { dz[m / 2] += rd2(pr, m) + ac[m / 2]; pin(dz[m / 2]); }
     }
+    }
     STAMP(20); DSTOP(20);
     // ---- extremestats + SignalEstimator of both outputs (dsp_icpc.jl:170-171,177-178): value first, then its first index
     float mxc = -INFINITY, mxz = -INFINITY;
@@ -1245,14 +1259,14 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       }
       LDSP_DPP_GROUP4("v_add_f32_dpp", pc, "v_add_f32_dpp", pz_, "v_max_f32_dpp", mxc, "v_max_f32_dpp", mxz);
       if (lane == 63) {
-        S.wsum[(W_CZ + 0) * NW + wave] = pc; S.wsum[(W_CZ + 1) * NW + wave] = pz_;
-        atomicMax(&S.sl->fmx[FX_CUSP], ford(mxc)); atomicMax(&S.sl->fmx[FX_ZAC], ford(mxz));
+        if (WC) { S.wsum[(W_CZ + 0) * NW + wave] = pc; atomicMax(&S.sl->fmx[FX_CUSP], ford(mxc)); }
+        if (WZ) { S.wsum[(W_CZ + 1) * NW + wave] = pz_; atomicMax(&S.sl->fmx[FX_ZAC], ford(mxz)); }
       }
     }
     __syncthreads();
     {
       const float vc = ford_inv(S.sl->fmx[FX_CUSP]), vz = ford_inv(S.sl->fmx[FX_ZAC]);
-      if (__ballot(own_c == vc || own_z == vz) != 0ull) {   // only the waves that hold a maximum look its index up
+      if (__ballot((WC && own_c == vc) || (WZ && own_z == vz)) != 0ull) {   // only the waves that hold a maximum look its index up
         int bc = 0x7fffffff, bz = 0x7fffffff;
 #pragma unroll
         for (int m = SP - 1; m >= 0; --m) {   // findmax: first occurrence
@@ -1261,13 +1275,13 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
           bc = (in && a == vc) ? tid + NT * m : bc;
           bz = (in && z == vz) ? tid + NT * m : bz;
         }
-        if (bc != 0x7fffffff) atomicMin(&S.sl->imin[IM_CUSP], bc);
-        if (bz != 0x7fffffff) atomicMin(&S.sl->imin[IM_ZAC], bz);
+        if (WC && bc != 0x7fffffff) atomicMin(&S.sl->imin[IM_CUSP], bc);
+        if (WZ && bz != 0x7fffffff) atomicMin(&S.sl->imin[IM_ZAC], bz);
       }
     }
     STAMP(21); DSTOP(21);
     __syncthreads();
-    if (tid < 2) {
+    if (tid < 2 && (tid == 0 ? WC : WZ)) {
       const int f = tid;
       float s = 0.f;
       for (int ww = 0; ww < NW; ++ww) s += S.wsum[(W_CZ + f) * NW + ww];
@@ -1278,6 +1292,32 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       S.outv[f ? C_e_zac_max : C_e_cusp_max] = (float)((double)v + back);
       S.outv[f ? C_t_zac_max : C_t_cusp_max] = P.t_first + P.dt * (float)(i + Lf - 1);
     }
+  };
+  using T_ = std::true_type; using F_ = std::false_type;
+  if (P.cz_shared) {   // (block-uniform)
+    cz_pass(T_{}, T_{}, P.cusp, P.zac, S.misc[12]);
+  } else {
+    cz_pass(T_{}, F_{}, P.cusp, P.zac, S.misc[12]);
+    // put T back (the pass turned B into the anti-causal scan and left A = y alone): the statements of phase 4
+    __syncthreads();
+    {
+      float tin[R], tt[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        y[r] = *reinterpret_cast<const f4*>(&S.A[4 * (tid + NT * r)]);   // A still holds y (the CUSP pass does not write it); read back so
+        const f2 t = y[r].xy + y[r].zw; tt[r] = t.x + t.y; tin[r] = tt[r];   // that the registers are free during that pass
+      }
+      LDSP_DPP_GROUP4("v_add_f32_dpp", tin[0], "v_add_f32_dpp", tin[1], "v_add_f32_dpp", tin[2], "v_add_f32_dpp", tin[3]);
+      float* pb = S.part + R * NW;
+      if (lane == 63) *reinterpret_cast<f4*>(&pb[4 * wave]) = (f4){tin[0], tin[1], tin[2], tin[3]};
+      __syncthreads();
+      float* scn2 = reinterpret_cast<float*>(S.dpart);
+      t_offsets_scan<NW>(pb, scn2 + R * NW, &S.B[Lp], wave, lane);
+      __syncthreads();
+      t_rows_store<NT>(y, tin, tt, scn2 + R * NW, S.B, tid, wave);
+    }
+    __syncthreads();
+    cz_pass(F_{}, T_{}, P.zac, P.zac, S.misc[13]);
   }
   STAMP(22); DSTOP(22);
   // ------------------------------------------------------------------------------------------------ outputs

@@ -395,16 +395,16 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, int r2, Ic
   return LDSP_OK;
 }
 
-// the lean kernels (icpc_lean.hip) cover the standard geometry: the trace fills the tile, CUSP and ZAC share their geometry
-// (closed form), the inverted t0 uses the same trapezoid, tx_mintot = 2 samples, Savitzky-Golay windows of at most 13 taps,
+// the lean kernels (icpc_lean.hip) cover the standard geometry: the trace fills the tile, CUSP and ZAC in closed form (sharing
+// their geometry: one pass; optimised separately: one pass each inside the same launch), the inverted t0 uses the same trapezoid, tx_mintot = 2 samples, Savitzky-Golay windows of at most 13 taps,
 // two traces per CU.  ldsp_icpc_run and ldsp_icpc_pz_trap_run decide alike, so that config 2's columns stay bit-identical
 // to the fused chain's.
 static bool icpc_lean_applies(const ldsp_ctx* c) {
   const IcpcDev& H = c->icpc_host;
   const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
   return !c->icpc_generic && !c->two_kernel && (c->dbg_stop == 0 || c->dbg_stop >= 100) && H.R == 4 && H.L == 16 * H.NT && H.cusp_mode == 1 &&
-         H.cz_shared && H.t0inv_same && H.tx_mintot == 2 && sg_max <= 13 &&
-         icpc_lean_smem_bytes(H.NT, H.cusp.Lf) <= 80640;   // two traces per CU (160 KiB LDS, 1280-byte granules)
+         H.t0inv_same && H.tx_mintot == 2 && sg_max <= 13 &&
+         icpc_lean_smem_bytes(H.NT, std::max(H.cusp.Lf, H.zac.Lf)) <= 80640;   // two traces per CU (160 KiB LDS, 1280-byte granules)
 }
 
 static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p) {
@@ -474,7 +474,7 @@ int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_
   const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
   const bool lean_ok = icpc_lean_applies(c) && !main_only;
   if (lean_ok) {
-    HIP_TRY(launch_icpc_lean(wf, n, H.NT, sg_max, c->d_icpc, od, ext_bl, ext_bl_scale, H.cusp.Lf, c->stream));
+    HIP_TRY(launch_icpc_lean(wf, n, H.NT, sg_max, c->d_icpc, od, ext_bl, ext_bl_scale, std::max(H.cusp.Lf, H.zac.Lf), c->stream));
     c->last_kernel = "lean::icpc_lean_kernel";
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
     return LDSP_OK;

@@ -211,3 +211,21 @@ def test_threshold_crossings_with_spikes_before_the_pulse(orc, params):
             assert bad.sum() == 0, (generic, c, np.nonzero(bad)[0], a[bad], b[bad])
         # the spikes did what they were meant to: traces 0..15 keep their crossing at the pulse, 16..23 moved to the spike pair
         assert np.all(gpu["t10"][:16] > 40.0) and np.all(gpu["t10"][16:24] < 20.0)
+
+def test_separately_optimised_cusp_and_zac_run_in_the_lean_launch(orc):
+    """pars_filter with different rise / flat-top times for CUSP and ZAC (what an optimisation campaign produces): the lean
+    kernel evaluates the two filters in two passes of its closed-form stage inside the SAME launch (y and T put back in
+    between); the generic path needs three launches.  Both against the oracle, and the launch really is the lean kernel."""
+    us = ldsp.us
+    pf = {"cusp": {"rt": 4.0 * us, "ft": 1.5 * us}, "zac": {"rt": 5.5 * us, "ft": 2.0 * us}}
+    p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * us, pf, L, 0.0, 16.0)
+    assert p.cusp.length != p.zac.length or p.cusp.flat != p.zac.flat
+    wf = ldsp.synth.hpge_batch(256, L, device="cuda", seed=31)
+    host = wf.cpu().numpy()
+    ora = orc.dsp_icpc(host, p, nthreads=16)
+    ctx = ldsp.default_context()
+    for generic, name in ((0, "lean::icpc_lean_kernel"), (1, "icpc_kernel")):
+        gpu = _run(wf, p, generic=generic)
+        assert ctx.last_kernel_name() == name
+        lines, worst = parity.compare(gpu, ora, wf=host, params=p, orc=orc)
+        assert worst <= parity.FLIP_FRAC, "\n".join(lines)

@@ -1,0 +1,18 @@
+"""dsp_icpc throughput for parameter sets the lean kernel does and does not take: shared CUSP/ZAC geometry (the reference's
+test configuration) vs separately optimised rise / flat-top times per filter (pars_filter), L = 8192.  usage: [n]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import legenddsp_jl_amd as ldsp
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+L, us = 8192, ldsp.us
+wf = ldsp.synth.hpge_batch(n, L, device="cuda")
+ctx = ldsp.default_context(); ctx.enable_timing(True)
+cases = {"test configuration (CUSP = ZAC geometry)": {},
+         "separate rise times: cusp rt 4.0 / zac rt 5.5 us": {"cusp": {"rt": 4.0 * us, "ft": 1.5 * us}, "zac": {"rt": 5.5 * us, "ft": 1.5 * us}},
+         "separate flat tops: cusp ft 1.0 / zac ft 2.0 us": {"cusp": {"rt": 5.0 * us, "ft": 1.0 * us}, "zac": {"rt": 5.0 * us, "ft": 2.0 * us}}}
+for name, pf in cases.items():
+    p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * us, pf, L, 0.0, 16.0)
+    ldsp.icpc_run(wf, p, ctx); torch.cuda.synchronize()
+    ms = min((ldsp.icpc_run(wf, p, ctx), ctx.last_kernel_ms())[1] for _ in range(3))
+    print(f"{name:55s} {ctx.last_kernel_name():24s} {ms:.3f} ms -> {n / ms * 1e3 / 1e6:.2f} M waveforms/s")
