@@ -279,7 +279,9 @@ __device__ __forceinline__ void t_rows_store(const f4 (&y)[R], const float (&tin
 }
 
 
-template <int NT, int M>
+// SEP: CUSP and ZAC have their own geometry (two passes of the closed-form stage); a separate instantiation, so that the usual
+// shared-geometry kernel keeps its register allocation
+template <int NT, int M, bool SEP>
 __global__ void __launch_bounds__(NT, 4)
 icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOutDev out, const float* __restrict__ ext_bl,
                  float ext_bl_scale) {
@@ -1294,7 +1296,7 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
     }
   };
   using T_ = std::true_type; using F_ = std::false_type;
-  if (P.cz_shared) {   // (block-uniform)
+  if constexpr (!SEP) {
     cz_pass(T_{}, T_{}, P.cusp, P.zac, S.misc[12]);
   } else {
     cz_pass(T_{}, F_{}, P.cusp, P.zac, S.misc[12]);
@@ -1479,13 +1481,13 @@ static hipError_t launch_pz_t(const float* wf, int64_t n, const IcpcDev* dP, flo
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT, int M>
+template <int NT, int M, bool SEP>
 static hipError_t launch_t(const float* wf, int64_t n, const IcpcDev* dP, const IcpcOutDev& out, const float* ext_bl, float ext_bl_scale,
                            int Lf, hipStream_t st) {
   const size_t smem = Smem<NT>::bytes(cz_pad_floats(Lf));
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_lean_kernel<NT, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_lean_kernel<NT, M, SEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((icpc_lean_kernel<NT, M>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, out, ext_bl, ext_bl_scale);
+  hipLaunchKernelGGL((icpc_lean_kernel<NT, M, SEP>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, out, ext_bl, ext_bl_scale);
   return hipGetLastError();
 }
 
@@ -1518,15 +1520,16 @@ hipError_t launch_pz_trap_lean(const float* wf, int64_t n, int NT, const IcpcDev
 }
 
 // sg_slots: 7 or 13 (the smallest that holds the three Savitzky-Golay windows)
-hipError_t launch_icpc_lean(const float* wf, int64_t n, int NT, int sg_slots, const IcpcDev* dP, const IcpcOutDev& out, const float* ext_bl,
-                            float ext_bl_scale, int Lf, hipStream_t st) {
+hipError_t launch_icpc_lean(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, const IcpcDev* dP, const IcpcOutDev& out,
+                            const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st) {
 #ifdef LDSP_DEV_512
 #define LDSP_LEAN_CASES LDSP_CASE(512)
 #else
 #define LDSP_LEAN_CASES LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512) LDSP_CASE(1024)
 #endif
 #define LDSP_CASE(N) \
-  case N: return sg_slots <= 7 ? lean::launch_t<N, 7>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st) : lean::launch_t<N, 13>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st);
+  case N: return cz_shared ? (sg_slots <= 7 ? lean::launch_t<N, 7, false>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st) : lean::launch_t<N, 13, false>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st)) \
+                           : (sg_slots <= 7 ? lean::launch_t<N, 7, true>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st) : lean::launch_t<N, 13, true>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st));
   switch (NT) {
     LDSP_LEAN_CASES
     default: return hipErrorInvalidValue;

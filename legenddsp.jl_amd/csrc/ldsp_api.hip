@@ -19,8 +19,8 @@ namespace ldsp {
 hipError_t launch_icpc(const float* wf, int64_t n, int NT, int R, bool full, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
                        const float* ext_bl, float ext_bl_scale, bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid,
                        int* stages);
-hipError_t launch_icpc_lean(const float* wf, int64_t n, int NT, int sg_slots, const IcpcDev* dP, const IcpcOutDev& out, const float* ext_bl,
-                            float ext_bl_scale, int Lf, hipStream_t st);
+hipError_t launch_icpc_lean(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, const IcpcDev* dP, const IcpcOutDev& out,
+                            const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st);
 size_t icpc_lean_smem_bytes(int NT, int Lf);
 hipError_t launch_pz_trap_lean(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
@@ -474,7 +474,7 @@ int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_
   const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
   const bool lean_ok = icpc_lean_applies(c) && !main_only;
   if (lean_ok) {
-    HIP_TRY(launch_icpc_lean(wf, n, H.NT, sg_max, c->d_icpc, od, ext_bl, ext_bl_scale, std::max(H.cusp.Lf, H.zac.Lf), c->stream));
+    HIP_TRY(launch_icpc_lean(wf, n, H.NT, sg_max, H.cz_shared != 0, c->d_icpc, od, ext_bl, ext_bl_scale, std::max(H.cusp.Lf, H.zac.Lf), c->stream));
     c->last_kernel = "lean::icpc_lean_kernel";
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
     return LDSP_OK;
