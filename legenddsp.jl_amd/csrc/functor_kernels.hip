@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(256) k_intersect_maximum(const float* __restri
 // So: pos_0 by the block's bit-mask Intersect, then one WAVE per threshold, 64 samples per step by ballot, starting
 // from the wave's previous crossing.  Thresholds that do not ascend (negative maximum, unsorted ratios) or
 // min_n > 32 take the reference's serial walk on one lane.
-__global__ void __launch_bounds__(256) k_multi_intersect(const float* __restrict__ x, int L, float t_first, float dt,
+__global__ void __launch_bounds__(512) k_multi_intersect(const float* __restrict__ x, int L, float t_first, float dt,
                                                          const float* __restrict__ tab, int K, int min_n, int half_n, int m,
                                                          int force_serial, float* __restrict__ xout, int32_t* __restrict__ status) {
   extern __shared__ __align__(16) unsigned char raw[];
@@ -752,7 +752,7 @@ int ldsp_multi_intersect(ldsp_ctx* c, const float* x, int64_t n, int32_t L, doub
   }
   if ((rc = upload_coef(c, tab))) return rc;
   if ((rc = set_lds(k_multi_intersect, b))) return rc;
-  hipLaunchKernelGGL(k_multi_intersect, dim3((unsigned)n), dim3(256), b, c->stream, x, L, (float)t_first, (float)dt,
+  hipLaunchKernelGGL(k_multi_intersect, dim3((unsigned)n), dim3(512), b, c->stream, x, L, (float)t_first, (float)dt,
                      (const float*)c->d_coef, K, min_n, half_n, m, c->multi_serial ? 1 : 0, xout, status);
   LAUNCH_CHECK();
   return LDSP_OK;
