@@ -55,6 +55,11 @@ struct CuspZacDev {
   int32_t zu_n;
   int32_t zu_shift[12], zu_shift_b[12];
   float zu_coef[12];
+  // the same sum as ONE chain over all shifts s_0 < s_1 < ... (links with a zero running sum included): a kernel that keeps
+  // Dp[n - s_e] in registers reads every shift once — u[n] = sum_e zc_r[e] * (Dp[n - zc_s[e]] - Dp[n - zc_s[e+1]])
+  int32_t zc_n;          // number of shifts (links = zc_n - 1)
+  int32_t zc_s[13];
+  float zc_r[12];
   // sum of the direct-form taps: the filter's response to a constant level.  The closed form runs on y - c (c = the level at
   // the left edge of the pick-off window) and adds c * hsum back at the end, see cz_body / icpc_lean.hip phase 7
   double hsum;

@@ -1084,12 +1084,33 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       f2 u[SP / 2];
 #pragma unroll
       for (int m = 0; m < SP / 2; ++m) u[m] = splat(0.f);
+      if (ZZ.zc_n == 9) {   // (block-uniform) the usual tap structure: one chain, every shift read once, links unrolled
+        f2 prev[SP / 2];
+        {
+          const float* dp = &S.B[tid - ZZ.zc_s[0]];
+#pragma unroll
+          for (int m = 0; m < SP; m += 2) prev[m / 2] = rd2(dp, m);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const f2 ce = splat(ZZ.zc_r[e]);
+          const float* dq = &S.B[tid - ZZ.zc_s[e + 1]];
+#pragma unroll
+          for (int m = 0; m < SP; m += 2) {
+            const f2 cur = rd2(dq, m);
+            u[m / 2] = fma2(ce, prev[m / 2] - cur, u[m / 2]);
+            prev[m / 2] = cur;
+          }
+          pin(u[0]);
+        }
+      } else {
       const int nz = ZZ.zu_n;
       for (int e = 0; e < nz; ++e) {
         const f2 ce = splat(ZZ.zu_coef[e]);
         const float *dp = &S.B[tid - ZZ.zu_shift[e]], *dq = &S.B[tid - ZZ.zu_shift_b[e]];
 #pragma unroll
         for (int m = 0; m < SP; m += 2) { u[m / 2] = fma2(ce, rd2(dp, m) - rd2(dq, m), u[m / 2]); pin(u[m / 2]); }
+      }
       }
 #pragma unroll
       for (int m = 0; m < SP; m += 2) { S.A[tid + NT * m] = u[m / 2].x; S.A[tid + NT * (m + 1)] = u[m / 2].y; }   // own elements: race-free

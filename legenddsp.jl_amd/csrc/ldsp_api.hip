@@ -294,6 +294,15 @@ static bool make_cuspzac(const ldsp_cuspzac& p, bool zac, CuspZacDev& d) {
   for (auto& t : terms) total += t.second;
   if (std::fabs(total) > 1e-6) return false;
   d.zu_n = 0;
+  d.zc_n = (int)terms.size();
+  {
+    double rr = 0;
+    for (size_t e = 0; e < terms.size(); ++e) {
+      d.zc_s[e] = terms[e].first;
+      rr += terms[e].second;
+      if (e + 1 < terms.size()) d.zc_r[e] = (float)(std::fabs(rr) <= 1e-9 ? 0.0 : rr);
+    }
+  }
   for (size_t e = 0; e + 1 < terms.size(); ++e) {
     run += terms[e].second;
     if (std::fabs(run) <= 1e-9) continue;
