@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LDSP_ABI_VERSION 2
+#define LDSP_ABI_VERSION 3
 
 typedef enum {
   LDSP_OK = 0,
@@ -249,12 +249,15 @@ int ldsp_icpc_run(ldsp_ctx* ctx, const float* wf, int64_t n,
  *                         signalstats(bl_window).mean; blmean then reports that value.
  *   main_only != 0:       run without the CUSP/ZAC stage: e_cusp, e_zac, e_cusp_max, e_zac_max, t_cusp_max, t_zac_max are
  *                         not written (the windowed traces are shorter than those filters).
+ *   in_u16 != 0:          `wf` points to uint16 ADC counts ([n][L], the element type of production waveforms) instead of
+ *                         float32: the kernel converts them as it loads them (the reference's shift_waveform promotes the
+ *                         samples to float the same way, src/dsp_icpc.jl:105); no separate cast pass, half the bytes read.
  * opts == NULL is ldsp_icpc_run. */
 typedef struct {
   const float* ext_baseline;
   double ext_baseline_scale;
   int32_t main_only;
-  int32_t _pad;
+  int32_t in_u16;
 } ldsp_icpc_opts;
 int ldsp_icpc_run_opts(ldsp_ctx* ctx, const float* wf, int64_t n, const ldsp_icpc_params* p,
                        const ldsp_icpc_opts* opts, const ldsp_icpc_out* out);

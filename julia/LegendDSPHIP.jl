@@ -21,7 +21,7 @@ import RadiationDetectorDSP: fltinstance, rdfilt!, flt_output_length, flt_input_
     flt_output_time_axis, smplinfo, SamplingInfo, AbstractRadSigFilterInstance, LinearFiltering, NonlinearFiltering
 
 const libldsp = get(ENV, "LDSP_HIP_LIB", joinpath(@__DIR__, "..", "legenddsp.jl_amd", "csrc", "libldsp_hip.so"))
-const LDSP_ABI_VERSION = 2
+const LDSP_ABI_VERSION = 3
 const LDSP_MAX_TRIG = 64
 const LDSP_ICPC_NCOLS = 48
 
@@ -98,7 +98,7 @@ struct LdspIcpcOpts
     ext_baseline::Ptr{Float32}
     ext_baseline_scale::Float64
     main_only::Int32
-    _pad::Int32
+    in_u16::Int32
 end
 
 struct LdspSipmParams
@@ -317,7 +317,7 @@ function LegendDSP.dsp_icpc(data::Table, config::DSPConfig, τ::Quantity, pars_f
         check(ccall((:ldsp_icpc_run, libldsp), Cint,
                     (Ptr{Cvoid}, Ptr{Float32}, Int64, Ref{LdspIcpcParams}, Ref{LdspIcpcOut}),
                     ctx.h, devptr(x), n, Ref(p), Ref(out)))
-    else
+    else    # e.g. LdspIcpcOpts(C_NULL, 1.0, 0, 1) with the UInt16 ADC counts reinterpreted: the kernel converts as it loads
         check(ccall((:ldsp_icpc_run_opts, libldsp), Cint,
                     (Ptr{Cvoid}, Ptr{Float32}, Int64, Ref{LdspIcpcParams}, Ref{LdspIcpcOpts}, Ref{LdspIcpcOut}),
                     ctx.h, devptr(x), n, Ref(p), Ref(opts), Ref(out)))

@@ -4,7 +4,7 @@ Pure declarations: importing this module loads no native code.
 """
 import ctypes as C
 
-LDSP_ABI_VERSION = 2
+LDSP_ABI_VERSION = 3
 LDSP_OK = 0
 LDSP_ERR_INVALID_ARG = -1
 LDSP_ERR_WINDOW = -2
@@ -110,7 +110,7 @@ class SipmParams(C.Structure):
 
 class IcpcOpts(C.Structure):
     """ldsp_icpc_opts: per-call variations of ldsp_icpc_run_opts (explicit arguments, no context state)."""
-    _fields_ = [("ext_baseline", C.c_void_p), ("ext_baseline_scale", C.c_double), ("main_only", C.c_int32), ("_pad", C.c_int32)]
+    _fields_ = [("ext_baseline", C.c_void_p), ("ext_baseline_scale", C.c_double), ("main_only", C.c_int32), ("in_u16", C.c_int32)]
 
 
 class TrigOut(C.Structure):

@@ -131,6 +131,7 @@ struct IcpcDev {
   int32_t cz_shared;  // cusp and zac share sigma/flat/length/tau: one set of recursions
   int32_t cusp_mode;  // 0 = direct-form FIR (comparator), 1 = closed-form recursions
   int32_t dbg_stop;   // profiling aid: return after phase N (0 = run everything)
+  int32_t in_u16;     // the traces are uint16 ADC counts (ldsp_icpc_opts.in_u16): converted to float as they are loaded
   const float* h_cusp; // device, true-convolution taps (mode 0)
   const float* h_zac;
   // lean kernel: how window w (0 bl, 1 tail, 2 SG baseline, 3 current window of SG filter 0, 4 union of the other current

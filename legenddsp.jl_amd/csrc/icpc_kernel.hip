@@ -664,7 +664,8 @@ icpc_cz_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, con
   ptx[1].fp = aux[4 * (size_t)blockIdx.x + 2];
 
   float y[R][4];
-  load_trace_s4<NT, R, FULL>(w, L, tid, y);
+  if (P.in_u16) load_trace_s4_u16<NT, R, FULL>(reinterpret_cast<const uint16_t*>(wf) + (size_t)blockIdx.x * (size_t)L, L, tid, y);
+  else load_trace_s4<NT, R, FULL>(w, L, tid, y);
   for (int i = tid; i < EST_TBL; i += NT) S.estB[i] = P.sig_est.B[i];
   if (tid < (int)(sizeof(Slots) / 4)) {  // fmx[0..1] (maxima: identity 0) and imin[0..1] (first index: identity INT_MAX) are used here
     const int o = tid * 4;
@@ -733,7 +734,10 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
 
   // ------------------------------------------------------------ phase 0: load
   float x[R][4];
-  load_trace_s4<NT, R, FULL>(w, L, tid, x);
+  const uint16_t* w16 = reinterpret_cast<const uint16_t*>(wf) + (size_t)blockIdx.x * (size_t)L;   // (in_u16)
+  auto wv = [&](int i) { return P.in_u16 ? (float)w16[i] : w[i]; };
+  if (P.in_u16) load_trace_s4_u16<NT, R, FULL>(w16, L, tid, x);
+  else load_trace_s4<NT, R, FULL>(w, L, tid, x);
   for (int i = tid; i < 2 * EST_TBL; i += NT) S.estB[i] = (i < EST_TBL) ? P.sig_est.B[i] : P.int_est.B[i - EST_TBL];
   if (tid < (int)(sizeof(Slots) / 4)) {  // reduction slots: identities
     uint32_t* raw = reinterpret_cast<uint32_t*>(S.sl);
@@ -747,7 +751,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   if (tid < 64) S.B1[Lp + tid] = 0.f;
 
   // ------------------------------------------------- phase 1: raw-trace stats
-  const float pv_bl = w[P.bl.from];  // pivot of the baseline sums: the window's first sample (uniform scalar load)
+  const float pv_bl = wv(P.bl.from);  // pivot of the baseline sums: the window's first sample (uniform scalar load)
   {
     float rmax = -INFINITY, rmin = INFINITY;
     WinAccF bl = {0, 0, 0};
@@ -854,7 +858,7 @@ icpc_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float*
   // shift_waveform(-blmean) (dsp_icpc.jl:105); tailstats on the shifted trace
   // (src/tailstats.jl:22-72); cumsum for the pole-zero correction
   double s_off[R];
-  const float pv_tl = __logf(fmaxf(w[P.tail.from] - blmean, 1e-30f));  // pivot of the log sums: the window's first sample
+  const float pv_tl = __logf(fmaxf(wv(P.tail.from) - blmean, 1e-30f));  // pivot of the log sums: the window's first sample
   {
     WinAccF tl = {0, 0, 0};
     int tail_bad = 0;

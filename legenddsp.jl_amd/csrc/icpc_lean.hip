@@ -307,9 +307,20 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
   // ------------------------------------------------------------------------------------------------ phase 0: load
   STAMP(0); DSTOP(0);
   f4 x[R];
+  // uint16 ADC counts (ldsp_icpc_opts.in_u16) are converted as they are loaded: no separate cast pass over HBM
+  const uint16_t* w16 = reinterpret_cast<const uint16_t*>(wf) + (size_t)blockIdx.x * (size_t)L;
+  auto wv = [&](int i) { return P.in_u16 ? (float)w16[i] : w[i]; };
+  if (P.in_u16) {   // (block-uniform)
 #pragma unroll
-  for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
-  const float pv_bl = w[P.bl.from];      // pivot of the baseline sums: the window's first sample
+    for (int r = 0; r < R; ++r) {
+      const uint2 q = *reinterpret_cast<const uint2*>(w16 + 4 * (tid + NT * r));
+      x[r] = (f4){(float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16)};
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
+  }
+  const float pv_bl = wv(P.bl.from);      // pivot of the baseline sums: the window's first sample
   for (int i = tid; i < 2 * EST_TBL; i += NT)   // LSQ basis tables of the two estimators -> LDS
     S.estB[i] = (i < EST_TBL) ? P.sig_est.B[i] : P.int_est.B[i - EST_TBL];
   if (tid < (int)(sizeof(Slots) / 4)) {
@@ -422,7 +433,7 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
 
   // ------------------------------------------------------- phase 2: shift, tailstats sums, cumulative sum for the pole-zero
   // shift_waveform(-blmean) (dsp_icpc.jl:105); tailstats on the shifted trace (src/tailstats.jl:22-72)
-  const float pv_tl = __logf(fmaxf(w[P.tail.from] - blmean, 1e-30f));   // pivot of the log sums
+  const float pv_tl = __logf(fmaxf(wv(P.tail.from) - blmean, 1e-30f));   // pivot of the log sums
   float inc[R], tot[R];
   {
     const f2 bm2 = splat(blmean);

@@ -416,8 +416,8 @@ static bool icpc_lean_applies(const ldsp_ctx* c) {
          icpc_lean_smem_bytes(H.NT, std::max(H.cusp.Lf, H.zac.Lf)) <= 80640;   // two traces per CU (160 KiB LDS, 1280-byte granules)
 }
 
-static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p) {
-  if (c->icpc_valid && c->icpc_mode_built == c->cusp_direct && !memcmp(&c->icpc_last, p, sizeof *p)) return LDSP_OK;
+static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p, int in_u16 = 0) {
+  if (c->icpc_valid && c->icpc_mode_built == c->cusp_direct && c->icpc_u16_built == in_u16 && !memcmp(&c->icpc_last, p, sizeof *p)) return LDSP_OK;
   std::vector<float> hc, hz;
   IcpcDev d;
   int rc = lower_icpc_dev(*p, c->cusp_direct, c->icpc_r2, d, hc, hz);
@@ -425,12 +425,13 @@ static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p) {
   d.h_cusp = c->d_hc; d.h_zac = c->d_hz;
   d.dbg_stop = c->dbg_stop;
   d.dbg_stamps = c->dbg_stamps;
+  d.in_u16 = in_u16;
   c->icpc_host = d;
   HIP_TRY(hipMemcpyAsync(c->d_icpc, &c->icpc_host, sizeof(IcpcDev), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_hc, hc.data(), sizeof(float) * hc.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_hz, hz.data(), sizeof(float) * hz.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));  // staging vectors die at return
-  c->icpc_last = *p; c->icpc_valid = true; c->icpc_mode_built = c->cusp_direct;
+  c->icpc_last = *p; c->icpc_valid = true; c->icpc_mode_built = c->cusp_direct; c->icpc_u16_built = in_u16;
   return LDSP_OK;
 }
 
@@ -459,11 +460,12 @@ int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_
   const bool main_only = opts && opts->main_only != 0;
   const float* ext_bl = opts ? opts->ext_baseline : nullptr;
   const float ext_bl_scale = opts ? (float)opts->ext_baseline_scale : 1.f;
+  const int in_u16 = (opts && opts->in_u16) ? 1 : 0;
   if (n < 0 || n > 0x7fffffffLL) return fail(LDSP_ERR_INVALID_ARG, "n = %lld out of range", (long long)n);
   if (n == 0) return LDSP_OK;
   if (!wf) return fail(LDSP_ERR_INVALID_ARG, "waveform pointer is NULL");
   ldsp_device_guard guard(c->device);
-  int rc = prepare_icpc(c, p);
+  int rc = prepare_icpc(c, p, in_u16);
   if (rc) return rc;
   IcpcOutDev od;
   static_assert(sizeof(ldsp_icpc_out) == sizeof(void*) * LDSP_ICPC_NCOLS + sizeof(int64_t), "ldsp_icpc_out layout");

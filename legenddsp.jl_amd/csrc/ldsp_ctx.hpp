@@ -39,6 +39,7 @@ struct ldsp_ctx {
   ldsp_icpc_params icpc_last{};
   bool icpc_valid = false;
   int icpc_mode_built = -1;
+  int icpc_u16_built = -1;   // the in_u16 flag the device copy of the parameter block was built with
   ldsp::IcpcDev icpc_host{};
   ldsp::IcpcDev* d_icpc = nullptr;
   float* d_hc = nullptr;

@@ -143,6 +143,33 @@ __device__ __forceinline__ void load_trace_s4(const float* __restrict__ w, int L
   }
 }
 
+// the same from uint16 ADC counts (production data; ldsp_icpc_opts.in_u16): 8-byte loads, converted in registers — no separate
+// cast pass over HBM (2L + 4L bytes per trace that the float path of a uint16 source pays before the first kernel)
+template <int NT, int R, bool FULL>
+__device__ __forceinline__ void load_trace_s4_u16(const uint16_t* __restrict__ w, int L, int tid, float (&x)[R][4]) {
+  if (FULL || (L & 3) == 0) {
+    uint2 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = 4 * (tid + NT * r);
+      v[r] = *reinterpret_cast<const uint2*>(w + (FULL ? i : max(min(i, L - 4), 0)));
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool ok = FULL || 4 * (tid + NT * r) < L;
+      x[r][0] = ok ? (float)(v[r].x & 0xffffu) : 0.f; x[r][1] = ok ? (float)(v[r].x >> 16) : 0.f;
+      x[r][2] = ok ? (float)(v[r].y & 0xffffu) : 0.f; x[r][3] = ok ? (float)(v[r].y >> 16) : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = 4 * (tid + NT * r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[r][e] = (i + e < L) ? (float)w[min(i + e, L - 1)] : 0.f;
+    }
+  }
+}
+
 
 // ---- bit-mask helpers ----------------------------------------------------------
 __device__ __forceinline__ void ballot_store(bool pred, uint32_t* bm, int word_base) {

@@ -61,7 +61,8 @@ def _as_device_f32(x: torch.Tensor, device) -> torch.Tensor:
 
 def icpc_run(wf: torch.Tensor, params: _abi.IcpcParams, ctx: _lib.Context = None, out: torch.Tensor = None,
              ext_baseline: torch.Tensor = None, ext_baseline_scale: float = 1.0, main_only: bool = False) -> torch.Tensor:
-    """Run the fused kernel on a device-resident [n, L] float32 batch.
+    """Run the fused kernel on a device-resident [n, L] batch: float32, or uint16 ADC counts (converted by the kernel as
+    it loads them — no separate cast pass; any other dtype is cast to float32 here).
 
     Returns the [n, 48] float32 output table (columns in `_abi.ICPC_COLS` order;
     the 5 integer columns hold int32 bit patterns — see `table_columns`).
@@ -74,7 +75,8 @@ def icpc_run(wf: torch.Tensor, params: _abi.IcpcParams, ctx: _lib.Context = None
     n, L = wf.shape
     if L != params.L:
         raise ValueError(f"waveform length {L} != params.L {params.L}")
-    wf = _as_device_f32(wf, wf.device)
+    in_u16 = wf.dtype == torch.uint16      # raw ADC counts: handed to the kernel as they are (converted while loading)
+    wf = wf.contiguous() if in_u16 else _as_device_f32(wf, wf.device)
     nc = len(_abi.ICPC_COLS)
     if out is None:
         out = torch.empty((n, nc), dtype=torch.float32, device=wf.device)
@@ -86,11 +88,11 @@ def icpc_run(wf: torch.Tensor, params: _abi.IcpcParams, ctx: _lib.Context = None
         setattr(o, c, base + 4 * i)
     o.stride = nc
     opts = None
-    if ext_baseline is not None or main_only:
+    if ext_baseline is not None or main_only or in_u16:
         if ext_baseline is not None and (ext_baseline.shape != (n,) or ext_baseline.dtype != torch.float32 or ext_baseline.device != wf.device
                                          or not ext_baseline.is_contiguous()):
             raise ValueError("ext_baseline must be a contiguous float32 [n] tensor on the waveforms' device")
-        opts = C.byref(_abi.IcpcOpts(None if ext_baseline is None else ext_baseline.data_ptr(), float(ext_baseline_scale), int(bool(main_only)), 0))
+        opts = C.byref(_abi.IcpcOpts(None if ext_baseline is None else ext_baseline.data_ptr(), float(ext_baseline_scale), int(bool(main_only)), int(in_u16)))
     ctx.bind_stream()
     _lib.check(_lib.lib().ldsp_icpc_run_opts(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params), opts, C.byref(o)))
     return out

@@ -229,3 +229,21 @@ def test_separately_optimised_cusp_and_zac_run_in_the_lean_launch(orc):
         assert ctx.last_kernel_name() == name
         lines, worst = parity.compare(gpu, ora, wf=host, params=p, orc=orc)
         assert worst <= parity.FLIP_FRAC, "\n".join(lines)
+
+
+@pytest.mark.parametrize("generic,two_kernel", [(0, 0), (1, 0), (0, 1)])
+def test_uint16_adc_counts_are_converted_by_the_kernel(params, generic, two_kernel):
+    """ldsp_icpc_opts.in_u16: the traces as uint16 ADC counts (what production waveforms are) give the table of the same
+    values passed as float32, bit for bit — the conversion happens in the kernel's load (lean, generic and two-launch form),
+    not in a separate cast pass."""
+    wf = ldsp.synth.hpge_batch(128, L, device="cuda", seed=41).round().clamp(0, 65535)
+    wf16 = wf.to(torch.uint16)
+    assert torch.equal(wf16.to(torch.float32), wf)
+    ctx = ldsp.default_context()
+    ctx.set_option("two_kernel", two_kernel)
+    try:
+        a, b = _run(wf, params, generic=generic), _run(wf16, params, generic=generic)
+    finally:
+        ctx.set_option("two_kernel", 0)
+    for c in ldsp._abi.ICPC_COLS:
+        assert np.array_equal(a[c], b[c], equal_nan=True), c

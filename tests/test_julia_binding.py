@@ -46,7 +46,7 @@ C_STRUCTS = {
                                                                               "sg_npts[2]", "sg_degree", "cur_left", "cur_right",
                                                                               "intrace_nsigma", "intrace_mintot", "_pad1", "bl_left", "bl_right"]),
     "ldsp_icpc_out": ("LdspIcpcOut", PTR48 + ["stride"]),
-    "ldsp_icpc_opts": ("LdspIcpcOpts", ["ext_baseline", "ext_baseline_scale", "main_only", "_pad"]),
+    "ldsp_icpc_opts": ("LdspIcpcOpts", ["ext_baseline", "ext_baseline_scale", "main_only", "in_u16"]),
     "ldsp_sipm_params": ("LdspSipmParams",
                          ["L", "_pad0", "t_first", "dt", "unit_per_us", "trunc_from", "trunc_until", "sg_npts", "sg_degree", "sg_mintot", "sg_maxtot",
                           "sg_min_thr", "sg_max_thr", "sg_nsigma", "sg_min_dc_thr", "sg_max_dc_thr", "sg_nsigma_dc", "pz_c"] + sub("trap", TRAP) +
