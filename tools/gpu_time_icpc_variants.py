@@ -16,3 +16,16 @@ for name, pf in cases.items():
     ldsp.icpc_run(wf, p, ctx); torch.cuda.synchronize()
     ms = min((ldsp.icpc_run(wf, p, ctx), ctx.last_kernel_ms())[1] for _ in range(3))
     print(f"{name:55s} {ctx.last_kernel_name():24s} {ms:.3f} ms -> {n / ms * 1e3 / 1e6:.2f} M waveforms/s")
+# uint16 ADC counts: converted in the kernel's load vs a separate cast pass before the float32 kernel
+p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * us, {}, L, 0.0, 16.0)
+w16 = wf.round().clamp(0, 65535).to(torch.uint16)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+def timed(fn):
+    fn(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); best = min(best, e0.elapsed_time(e1))
+    return best
+t_a = timed(lambda: ldsp.icpc_run(w16, p, ctx))
+t_b = timed(lambda: ldsp.icpc_run(w16.to(torch.float32), p, ctx))
+print(f"uint16 input, converted while loading: {t_a:.3f} ms -> {n / t_a * 1e3 / 1e6:.2f} M waveforms/s;  cast pass + float32 kernel: {t_b:.3f} ms -> {n / t_b * 1e3 / 1e6:.2f} M waveforms/s")
