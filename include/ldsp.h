@@ -317,6 +317,10 @@ int ldsp_icpc_pz_trap_run(ldsp_ctx* ctx, const float* wf, int64_t n,
 /* dsp_sipm(data, config, pars_optimization)       src/dsp_sipm.jl:47-158 */
 int ldsp_sipm_run(ldsp_ctx* ctx, const float* wf, int64_t n,
                   const ldsp_sipm_params* p, const ldsp_sipm_out* out);
+/* The same on uint16 ADC counts ([n][L]): converted to float as the kernel loads them (src/dsp_sipm.jl:87-88 promotes
+ * the samples the same way), no separate cast pass. */
+int ldsp_sipm_run_u16(ldsp_ctx* ctx, const uint16_t* wf, int64_t n,
+                      const ldsp_sipm_params* p, const ldsp_sipm_out* out);
 
 /* ---- filter functors: rdfilt!(y, fltinstance(flt, si), x) ---------------- */
 /* Output length of each filter = what flt_output_length(fi) returns. */

@@ -370,6 +370,19 @@ end
 TrigBuffers(n::Integer, cap::Integer) = TrigBuffers(ROCVector{Int32}(undef, n), (ROCArray{Float32}(undef, cap, n) for _ in 1:4)...)
 _trig_out(t::TrigBuffers) = LdspTrigOut(devptr(t.count), devptr(t.x), devptr(t.x_high), devptr(t.x_tot), devptr(t.max), Int32(size(t.x, 1)), Int32(0))
 
+# UInt16 ADC counts go through ldsp_sipm_run_u16 (converted by the kernel as it loads them)
+function _sipm_run(x::ROCArray{UInt16,2}, p::LdspSipmParams, ctx::LdspCtx, cap::Integer)
+    n = size(x, 2)
+    sc = ROCArray{Float32}(undef, n, 20)
+    groups = ntuple(_ -> TrigBuffers(n, cap), 4)
+    out = LdspSipmOut(ntuple(i -> Ptr{Float32}(UInt(pointer(sc)) + 4 * n * (i - 1)), 20), _trig_out.(groups)...)
+    check(ccall((:ldsp_sipm_run_u16, libldsp), Cint,
+                (Ptr{Cvoid}, Ptr{UInt16}, Int64, Ref{LdspSipmParams}, Ref{LdspSipmOut}),
+                ctx.h, devptr(x), n, Ref(p), Ref(out)))
+    synchronize!(ctx)
+    sc, groups
+end
+
 function _sipm_run(x::ROCArray{Float32,2}, p::LdspSipmParams, ctx::LdspCtx, cap::Integer)
     n = size(x, 2)
     sc = ROCArray{Float32}(undef, n, 20)

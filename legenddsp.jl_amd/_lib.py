@@ -71,6 +71,7 @@ def _declare(lib):
     # optional symbols (declared in include/ldsp.h; bound when present)
     opt = {
         "ldsp_sipm_run": [_VOIDP, _VOIDP, _I64, C.POINTER(_abi.SipmParams), C.POINTER(_abi.SipmOut)],
+        "ldsp_sipm_run_u16": [_VOIDP, _VOIDP, _I64, C.POINTER(_abi.SipmParams), C.POINTER(_abi.SipmOut)],
         "ldsp_rdfilt_invcr": [_VOIDP, _VOIDP, _I64, _I32, _DBL, _VOIDP],
         "ldsp_rdfilt_integrator": [_VOIDP, _VOIDP, _I64, _I32, _DBL, _VOIDP],
         "ldsp_rdfilt_trap": [_VOIDP, _VOIDP, _I64, _I32, _abi.Trap, _VOIDP],
@@ -105,7 +106,7 @@ DECLARED_SYMBOLS = [
     "ldsp_abi_version", "ldsp_abi_sizeof", "ldsp_ctx_create", "ldsp_ctx_destroy", "ldsp_ctx_set_stream",
     "ldsp_ctx_use_own_stream",
     "ldsp_ctx_synchronize", "ldsp_last_error_string", "ldsp_ctx_set_option", "ldsp_ctx_enable_timing",
-    "ldsp_ctx_last_kernel_ms", "ldsp_ctx_last_stage_ms", "ldsp_ctx_last_kernel_name", "ldsp_icpc_check_params", "ldsp_icpc_run", "ldsp_icpc_pz_trap_run", "ldsp_trap_grid_run", "ldsp_fir_grid_run", "ldsp_sg_grid_run", "ldsp_sipm_run",
+    "ldsp_ctx_last_kernel_ms", "ldsp_ctx_last_stage_ms", "ldsp_ctx_last_kernel_name", "ldsp_icpc_check_params", "ldsp_icpc_run", "ldsp_icpc_pz_trap_run", "ldsp_trap_grid_run", "ldsp_fir_grid_run", "ldsp_sg_grid_run", "ldsp_sipm_run", "ldsp_sipm_run_u16",
     "ldsp_rdfilt_invcr", "ldsp_rdfilt_integrator", "ldsp_rdfilt_trap", "ldsp_rdfilt_fir",
     "ldsp_rdfilt_derivative", "ldsp_rdfilt_haar", "ldsp_rdfilt_moving_window",
     "ldsp_rdfilt_moving_window_multi", "ldsp_rdfilt_affine", "ldsp_cusp_coeffs", "ldsp_zac_coeffs",

@@ -32,6 +32,7 @@ struct SipmDev {
   int32_t trap_mintot, trap_maxtot;
   float trap_min_thr, trap_max_thr, trap_nsigma, trap_min_dc, trap_max_dc, trap_nsigma_dc;
   int32_t dbg_stop;  // profiling aid: return after stage k (tools/gpu_time_sipm.py)
+  int32_t in_u16;    // the traces are uint16 ADC counts (ldsp_sipm_run_u16): converted as they are loaded
   long long* dbg_stamps;   // diagnostic build (-DLDSP_STAMPS, tools/dev_build_sipm.sh): s_memtime per wave at every SSTAMP
 };
 
@@ -81,7 +82,8 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
   auto put = [&](int c, float v) { if (tid == 0 && out.col[c]) out.col[c][b] = v; };
 
   // shift_waveform(wvfs, 0.0)  (dsp_sipm.jl:88) — values unchanged
-  tb::load_trace(wf + b * (size_t)L, A, L);
+  if (P.in_u16) tb::load_trace_u16(reinterpret_cast<const uint16_t*>(wf) + b * (size_t)L, A, L);
+  else tb::load_trace(wf + b * (size_t)L, A, L);
   for (int i = L + tid; i < pad4(L); i += NT) A[i] = 0.f;
   __syncthreads();
   {  // extremestats on the full trace and on TruncateFilter(t0_hpge_window)   :91-95
@@ -227,7 +229,14 @@ static hipError_t launch_s4(const float* wf, int64_t n, const SipmDev* d, const 
 
 using namespace ldsp;
 
+static int sipm_run_impl(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_sipm_params* p, const ldsp_sipm_out* out, int in_u16);
 extern "C" int ldsp_sipm_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_sipm_params* p, const ldsp_sipm_out* out) {
+  return sipm_run_impl(c, wf, n, p, out, 0);
+}
+extern "C" int ldsp_sipm_run_u16(ldsp_ctx* c, const uint16_t* wf, int64_t n, const ldsp_sipm_params* p, const ldsp_sipm_out* out) {
+  return sipm_run_impl(c, reinterpret_cast<const float*>(wf), n, p, out, 1);
+}
+static int sipm_run_impl(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_sipm_params* p, const ldsp_sipm_out* out, int in_u16) {
   if (!p || !out) return ldsp_fail(LDSP_ERR_INVALID_ARG, "ldsp_sipm_run: NULL argument");
   int rc = ldsp_check_batch(c, wf, n, p->L, "ldsp_sipm_run");
   if (rc || n == 0) return rc;
@@ -255,6 +264,7 @@ extern "C" int ldsp_sipm_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp
   d.trap_mintot = p->trap_mintot; d.trap_maxtot = p->trap_maxtot;
   d.trap_min_thr = (float)p->trap_min_thr; d.trap_max_thr = (float)p->trap_max_thr; d.trap_nsigma = (float)p->trap_nsigma;
   d.dbg_stop = c->dbg_stop;
+  d.in_u16 = in_u16;
   d.dbg_stamps = c->dbg_stamps;
   d.trap_min_dc = (float)p->trap_min_dc_thr; d.trap_max_dc = (float)p->trap_max_dc_thr; d.trap_nsigma_dc = (float)p->trap_nsigma_dc;
   sipm::SipmOutDev od;

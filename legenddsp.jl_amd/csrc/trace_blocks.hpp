@@ -101,6 +101,11 @@ __device__ __forceinline__ void load_trace(const float* __restrict__ g, float* s
     for (int i = tid; i < n; i += NT) s[i] = g[i];
   }
 }
+// the same from uint16 ADC counts (converted on the way)
+__device__ __forceinline__ void load_trace_u16(const uint16_t* __restrict__ g, float* s, int n) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  for (int i = tid; i < n; i += NT) s[i] = (float)g[i];
+}
 __device__ __forceinline__ void store_trace(float* __restrict__ g, const float* s, int n) {
   const int tid = threadIdx.x, NT = blockDim.x;
   if ((((uintptr_t)g) & 15) == 0) {

@@ -177,7 +177,8 @@ def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None
     n, L = wf.shape
     if L != params.L:
         raise ValueError(f"waveform length {L} != params.L {params.L}")
-    wf = _as_device_f32(wf, wf.device)
+    in_u16 = wf.dtype == torch.uint16      # raw ADC counts: handed to the kernel as they are (converted while loading)
+    wf = wf.contiguous() if in_u16 else _as_device_f32(wf, wf.device)
     dev = wf.device
     cap = int(cap) if cap else _abi.LDSP_MAX_TRIG
     if out is not None:
@@ -207,7 +208,8 @@ def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None
         setattr(o, g, _abi.TrigOut(t["count"].data_ptr(), t["x"].data_ptr(), t["x_high"].data_ptr(), t["x_tot"].data_ptr(), t["max"].data_ptr(),
                                    t["x"].shape[1], 0))
     ctx.bind_stream()
-    _lib.check(_lib.lib().ldsp_sipm_run(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params), C.byref(o)))
+    run = _lib.lib().ldsp_sipm_run_u16 if in_u16 else _lib.lib().ldsp_sipm_run
+    _lib.check(run(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params), C.byref(o)))
     return sc, trig
 
 

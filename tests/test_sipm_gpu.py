@@ -179,3 +179,26 @@ def test_sipm_more_triggers_than_the_slab(orc, generic):
             np.testing.assert_allclose(a, ora[grp]["x"][i, :oc[i]], atol=0.05, err_msg=f"{grp} trace {i}")
             m = res[cm][i].cpu().numpy().astype(np.float64)
             np.testing.assert_allclose(m, ora[grp]["max"][i, :oc[i]], atol=2e-3, rtol=1e-4, err_msg=f"{grp} trace {i}")
+
+
+@pytest.mark.parametrize("generic", [0, 1])
+def test_sipm_uint16_adc_counts_are_converted_by_the_kernel(generic):
+    """ldsp_sipm_run_u16: uint16 ADC counts give the scalars and triggers of the same values passed as float32, bit for
+    bit (register-resident and generic kernel)."""
+    n, L = 64, 16384
+    p = ldsp.lower_sipm(ldsp.reference_test_sipm_config(), {"sg": {"wl": 200 * ldsp.ns}}, L, 0.0, 16.0)
+    wf = (ldsp.synth.sipm_batch(n, L, device="cuda", seed=9) * 40.0 + 3000.0).round().clamp(0, 65535)
+    wf16 = wf.to(torch.uint16)
+    assert torch.equal(wf16.to(torch.float32), wf)
+    ctx = ldsp.default_context()
+    ctx.set_option("sipm_generic", generic)
+    try:
+        a, b = ldsp.sipm_run(wf, p, ctx), ldsp.sipm_run(wf16, p, ctx)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_option("sipm_generic", 0)
+    assert torch.equal(a[0].nan_to_num(), b[0].nan_to_num())
+    for g in ldsp._abi.SIPM_TRIG_GROUPS:
+        assert torch.equal(a[1][g]["count"], b[1][g]["count"]) and int(a[1][g]["count"].sum()) >= 0
+        for k in ("x", "x_high", "x_tot", "max"):
+            assert torch.equal(a[1][g][k].nan_to_num(), b[1][g][k].nan_to_num()), (g, k)
