@@ -41,6 +41,20 @@ namespace ldsp {
 namespace lean {
 
 typedef __attribute__((address_space(3))) float lds_float;   // explicit LDS pointers: survive being pinned to a VGPR (ds_ instructions, not flat_)
+typedef __attribute__((address_space(3))) float __attribute__((ext_vector_type(4))) lds_f4;
+// the NW per-wave partials of one quantity, summed / folded in wave order: for eight waves two 16-byte reads instead of eight 4-byte ones
+template <int NW, typename F>
+__device__ __forceinline__ float fold_partials(const lds_float* p, float init, F f) {
+  float acc = init;
+  if constexpr (NW == 8) {
+    const auto a = *(const lds_f4*)p, b = *(const lds_f4*)(p + 4);
+    acc = f(f(f(f(f(f(f(f(acc, a.x), a.y), a.z), a.w), b.x), b.y), b.z), b.w);
+  } else {
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) acc = f(acc, p[ww]);
+  }
+  return acc;
+}
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -368,9 +382,9 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
   // every thread: baseline mean and the raw extremes from the per-wave partials
   float blmean, raw_max, raw_min;
   {
-    float s = 0.f, mx = -INFINITY, mn = INFINITY;
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) { s += S.wred[ww]; mx = vmax(mx, S.wred[3 * NW + ww]); mn = vmin(mn, S.wred[4 * NW + ww]); }
+    const float s = fold_partials<NW>(S.wred, 0.f, [](float a, float b) { return a + b; });
+    const float mx = fold_partials<NW>(S.wred + 3 * NW, -INFINITY, [](float a, float b) { return vmax(a, b); });
+    const float mn = fold_partials<NW>(S.wred + 4 * NW, INFINITY, [](float a, float b) { return vmin(a, b); });
     blmean = fmaf(s, (float)P.bl.inv_n, pv_bl);
     if (ext_bl) blmean = ext_bl[blockIdx.x] * ext_bl_scale;   // windowed traces of dsp_icpc_compressed (dsp_icpc.jl:353)
     raw_max = mx; raw_min = mn;
@@ -661,9 +675,8 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
   // in-trace pile-up threshold (dsp_routines.jl:75-77) and t50_current threshold (dsp_icpc.jl:192)
   float thr_intr, thr_sg50;
   {
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) { s1 += S.wsum[(W_SGB + 0) * NW + ww]; s2 += S.wsum[(W_SGB + 1) * NW + ww]; }
+    const float s1 = fold_partials<NW>(S.wsum + (W_SGB + 0) * NW, 0.f, [](float a, float b) { return a + b; });
+    const float s2 = fold_partials<NW>(S.wsum + (W_SGB + 1) * NW, 0.f, [](float a, float b) { return a + b; });
     const float m_ = s1 * (float)P.sgbl.inv_n;
     const float var_ = fmaxf(fmaf(s2, (float)P.sgbl.inv_n, -m_ * m_), 0.f);
     thr_intr = __builtin_amdgcn_sqrtf(var_) * P.intrace_nsigma;
@@ -1077,6 +1090,12 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
     __syncthreads();
     STAMP(16); DSTOP(16);
     auto rd2 = [&](const float* p, int m) { return mk2(p[NT * m], p[NT * (m + 1)]); };
+    // rows m and m+1 of a lane-strided array in ONE ds_write2st64_b32 (hipcc leaves them as two ds_write_b32 with different base
+    // registers when the array lies behind the 64 KB an immediate offset reaches)
+    auto wr2 = [&](float* p, int m, f2 v) {
+      const uint32_t a = (uint32_t)(uintptr_t)(lds_float*)(p + NT * m);
+      asm volatile("ds_write2st64_b32 %0, %1, %2 offset1:%3" : : "v"(a), "v"(v.x), "v"(v.y), "n"(NT / 64) : "memory");
+    };
     // ---- flat top + last tap (LS); ZAC: u[n] = sum_e coef_e Dp[n - shift_e] -> A in place of y
     f2 ac[SP / 2], dz[SP / 2];
     {
@@ -1124,7 +1143,8 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       }
       }
 #pragma unroll
-      for (int m = 0; m < SP; m += 2) { S.A[tid + NT * m] = u[m / 2].x; S.A[tid + NT * (m + 1)] = u[m / 2].y; }   // own elements: race-free
+      for (int m = 0; m < SP; m += 2) wr2(&S.A[tid], m, u[m / 2]);   // own elements: race-free
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the compiler does not count the stores of an asm statement)
       }
     }
     STAMP(17); DSTOP(17);
