@@ -11,7 +11,7 @@
 //   * the scalar finishing work (statistics, parabolas, interpolations) is spread over different waves, in float32.
 // It computes the same 48 columns as icpc_kernel<NT, 4, true, true> (reference src/dsp_icpc.jl:62-230) and is used when
 // the trace fills the tile (L = 16 NT), CUSP and ZAC share their geometry (closed form), the three Savitzky-Golay windows
-// have at most M taps, the inverted t0 uses the same trapezoid and tx_mintot = 2 samples; every other configuration runs
+// have at most M taps, the inverted t0 uses the same trapezoid and tx_mintot <= 2 samples; every other configuration runs
 // icpc_kernel (option "icpc_generic" forces it: the comparator of tests/test_icpc_gpu.py).
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -684,10 +684,12 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
     thr_sg50 = ford_inv(S.sl->fmx[FX_G]) * 0.5f;
   }
   // LS pass over the SG output, two rows per step (ds_read2st64): the pile-up mask by ballot (a count of runs is needed),
-  // and t50_current (dsp_icpc.jl:192-195) directly: with tx_mintot = 2 a crossing at k is g[k-1] < thr <= min(g[k], g[k+1]).
+  // and t50_current (dsp_icpc.jl:192-195) directly: with tx_mintot = 2 a crossing at k is g[k-1] < thr <= min(g[k], g[k+1]),
+  // with tx_mintot = 1 (presummed traces of dsp_icpc_compressed) g[k-1] < thr <= g[k].
   {
     int code50 = SP;
     uint32_t acci = 0u;
+    const bool one = P.tx_mintot == 1;   // (block-uniform; the host sends tx_mintot <= 2 here)
     const float* gb = &S.B[tid];
 #pragma unroll
     for (int m = SP - 2; m >= 0; m -= 2) {
@@ -695,9 +697,9 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       f2 gm = mk2(gb[NT * m - 1], gb[NT * (m + 1) - 1]);
       if (m == 0 && tid == 0) gm.x = INFINITY;   // a run that starts the trace is no crossing
       const f2 gp = mk2(gb[NT * m + 1], gb[NT * (m + 1) + 1]);
-      const float w1 = (gm.y < thr_sg50) ? vmin(g.y, gp.y) : -INFINITY;
+      const float w1 = (gm.y < thr_sg50) ? (one ? g.y : vmin(g.y, gp.y)) : -INFINITY;
       code50 = (w1 >= thr_sg50) ? m + 1 : code50;
-      const float w0 = (gm.x < thr_sg50) ? vmin(g.x, gp.x) : -INFINITY;
+      const float w0 = (gm.x < thr_sg50) ? (one ? g.x : vmin(g.x, gp.x)) : -INFINITY;
       code50 = (w0 >= thr_sg50) ? m : code50;
       const unsigned long long ba = __ballot(g.x >= thr_intr), bb = __ballot(g.y >= thr_intr);
       put_ballots(acci, ba, bb, 2 * m);

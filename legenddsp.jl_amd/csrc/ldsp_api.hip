@@ -405,14 +405,14 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, int r2, Ic
 }
 
 // the lean kernels (icpc_lean.hip) cover the standard geometry: the trace fills the tile, CUSP and ZAC in closed form (sharing
-// their geometry: one pass; optimised separately: one pass each inside the same launch), the inverted t0 uses the same trapezoid, tx_mintot = 2 samples, Savitzky-Golay windows of at most 13 taps,
+// their geometry: one pass; optimised separately: one pass each inside the same launch), the inverted t0 uses the same trapezoid, tx_mintot <= 2 samples, Savitzky-Golay windows of at most 13 taps,
 // two traces per CU.  ldsp_icpc_run and ldsp_icpc_pz_trap_run decide alike, so that config 2's columns stay bit-identical
 // to the fused chain's.
 static bool icpc_lean_applies(const ldsp_ctx* c) {
   const IcpcDev& H = c->icpc_host;
   const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
   return !c->icpc_generic && !c->two_kernel && (c->dbg_stop == 0 || c->dbg_stop >= 100) && H.R == 4 && H.L == 16 * H.NT && H.cusp_mode == 1 &&
-         H.t0inv_same && H.tx_mintot == 2 && sg_max <= 13 &&
+         H.t0inv_same && H.tx_mintot <= 2 && sg_max <= 13 &&
          icpc_lean_smem_bytes(H.NT, std::max(H.cusp.Lf, H.zac.Lf)) <= 80640;   // two traces per CU (160 KiB LDS, 1280-byte granules)
 }
 
