@@ -651,27 +651,18 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
   STAMP(7); DSTOP(7);
   // filter f at output index k from y in LDS (the few samples the parabolas and crossing interpolations need)
   auto flt_at = [&](int f, int k) -> float {
-    if (f < 3) {
+    if (f < 3) {   // all M reads in flight together (taps beyond the filter's own read the margin and count as zero), summed in tap order
+      float a[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) a[i] = S.A[k + i];
+      asm volatile("" ::: "memory");
       float g = 0.f;
-      for (int i = 0; i < P.sg_npts[f]; ++i) g = fmaf(P.sg_c[f][i], S.A[k + i], g);
+#pragma unroll
+      for (int i = 0; i < M; ++i) g = fmaf(P.sg_c[f][i], (i < P.sg_npts[f]) ? a[i] : 0.f, g);
       return g;
     }
     return S.A[max(k, 1)] - S.A[max(k - 1, 0)];
   };
-  // get_wvf_maximum (src/interpolation.jl:30-46): parabola through the three samples about the maximum if it is strictly
-  // interior.  One wave (3, or the last); lane 3f+d+1 evaluates filter f at i_f+d.
-  if (wave == min(3, NW - 1)) {
-    const int f = min(lane / 3, 3), d = lane - 3 * f - 1;
-    const int fs = (f == 2 && P.sg_same_02) ? 0 : f;
-    float v; int i;
-    unpack_vi(S.sl->vi[VI_CUR0 + fs], &v, &i);
-    const bool interior = i > P.cur_from[fs] && i < P.cur_until[fs];
-    float ev = 0.f;
-    if (lane < 12 && interior) ev = flt_at(fs, i + d);
-    const float em = __shfl(ev, 3 * f), e0 = __shfl(ev, 3 * f + 1), ep = __shfl(ev, 3 * f + 2);
-    if (interior) v = extrema3points(em, e0, ep);
-    if (lane < 12 && d == -1) S.outv[f == 0 ? C_a_sg : f == 1 ? C_a_60 : f == 2 ? C_a_100 : C_a_raw] = v;
-  }
   // in-trace pile-up threshold (dsp_routines.jl:75-77) and t50_current threshold (dsp_icpc.jl:192)
   float thr_intr, thr_sg50;
   {
@@ -856,17 +847,44 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
   }
   __syncthreads();
   STAMP(12); DSTOP(12);
-  // Intersect scans on the bit-masks (thread <-> word): t0, inverted t0, in-trace pile-up
-  for (int j = tid; j < 2 * NWORDS; j += NT) {
-    const int q = j / NWORDS, wd = j % NWORDS;
+  // Intersect scans on the bit-masks (thread <-> word): t0, inverted t0, in-trace pile-up.  Every word a thread's scans can need is
+  // read first (one wait instead of a dependent LDS round trip per word), and the run tests are loop-free (intersect_pre /
+  // intersect_rev_pre); run lengths beyond their windows take the word-by-word forms.
+  static_assert(2 * NWORDS == NT, "one t0 / inverted-t0 word per thread");
+  if (P.t0_mintot <= 97 && P.intrace_mintot <= 32) {   // block-uniform
+    const int q = tid / NWORDS, wd = tid % NWORDS;
+    const uint32_t* b0 = S.bm + (M_T0 + q) * NWORDS;
+    const uint32_t* bi = S.bm + M_INTR * NWORDS;
+    const bool has_i = tid < NWORDS;   // (waves of the lower half also take an in-trace word)
+    uint32_t t[5], u[3];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t[k] = b0[min(max(wd + k - 1, 0), NWORDS - 1)];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[k] = bi[min(max(wd + k - 1, 0), NWORDS - 1)];
+    asm volatile("" ::: "memory");
+    if (wd == 0) { t[0] = 0u; u[0] = 0u; }
+#pragma unroll
+    for (int k = 2; k < 5; ++k) t[k] = (wd + k - 1 < NWORDS) ? t[k] : 0u;
+    u[2] = (wd + 1 < NWORDS) ? u[2] : 0u;
     int c, f;
-    intersect_word(S.bm + (M_T0 + q) * NWORDS, wd, NWORDS, P.t0_mintot, &c, &f);
+    intersect_pre(t[0], t[1], t[2], t[3], t[4], wd, P.t0_mintot, &c, &f);
     if (c) { atomicAdd(&S.sl->isum[IS_T0 + q], c); atomicMin(&S.sl->imin[IM_T0 + q], f); }
-  }
-  for (int wd = tid; wd < NWORDS; wd += NT) {
-    int c, f;
-    intersect_word_rev(S.bm + M_INTR * NWORDS, wd, NWORDS, ng, P.intrace_mintot, &c, &f);
-    if (c) { atomicAdd(&S.sl->isum[IS_INTR], c); atomicMax(&S.sl->imax[0], f); }
+    if (has_i) {
+      intersect_rev_pre(u[0], u[1], u[2], wd, ng, P.intrace_mintot, &c, &f);
+      if (c) { atomicAdd(&S.sl->isum[IS_INTR], c); atomicMax(&S.sl->imax[0], f); }
+    }
+  } else {
+    for (int j = tid; j < 2 * NWORDS; j += NT) {
+      const int q = j / NWORDS, wd = j % NWORDS;
+      int c, f;
+      intersect_word(S.bm + (M_T0 + q) * NWORDS, wd, NWORDS, P.t0_mintot, &c, &f);
+      if (c) { atomicAdd(&S.sl->isum[IS_T0 + q], c); atomicMin(&S.sl->imin[IM_T0 + q], f); }
+    }
+    for (int wd = tid; wd < NWORDS; wd += NT) {
+      int c, f;
+      intersect_word_rev(S.bm + M_INTR * NWORDS, wd, NWORDS, ng, P.intrace_mintot, &c, &f);
+      if (c) { atomicAdd(&S.sl->isum[IS_INTR], c); atomicMax(&S.sl->imax[0], f); }
+    }
   }
   __syncthreads();
   STAMP(13); DSTOP(13);
@@ -1029,6 +1047,22 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
         const float res = qdrift_wave(P.int_est, S.estB + EST_TBL, S.A, L, ips, fps, scr);
         if (lane == 0) eslot[is_lq ? 2 : 1] = res;
       }
+    }
+    // get_wvf_maximum of the four current signals (src/interpolation.jl:30-46): parabola through the three samples about the
+    // maximum if it is strictly interior.  One wave (3, or the last); lane 3f+d+1 evaluates filter f at i_f+d.  The arg-maxima
+    // come from the SG phase; the job runs here, next to the estimators of waves 0-2, because ahead of the LS pass the whole
+    // workgroup waited for it at the next barrier.
+    if (wave == min(3, NW - 1)) {
+      const int f = min(lane / 3, 3), d = lane - 3 * f - 1;
+      const int fs = (f == 2 && P.sg_same_02) ? 0 : f;
+      float v; int i;
+      unpack_vi(S.sl->vi[VI_CUR0 + fs], &v, &i);
+      const bool interior = i > P.cur_from[fs] && i < P.cur_until[fs];
+      float ev = 0.f;
+      if (lane < 12 && interior) ev = flt_at(fs, i + d);
+      const float em = __shfl(ev, 3 * f), e0 = __shfl(ev, 3 * f + 1), ep = __shfl(ev, 3 * f + 2);
+      if (interior) v = extrema3points(em, e0, ep);
+      if (lane < 12 && d == -1) S.outv[f == 0 ? C_a_sg : f == 1 ? C_a_60 : f == 2 ? C_a_100 : C_a_raw] = v;
     }
     __syncthreads();
     if (tid == 0) {

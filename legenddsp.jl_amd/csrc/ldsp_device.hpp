@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "wave_prims.hpp"
+#include "run_scan.hpp"
 
 namespace ldsp {
 
@@ -175,67 +176,6 @@ __device__ __forceinline__ void load_trace_s4_u16(const uint16_t* __restrict__ w
 __device__ __forceinline__ void ballot_store(bool pred, uint32_t* bm, int word_base) {
   unsigned long long m = __ballot(pred);
   if (lane_id() == 0) { bm[word_base] = (uint32_t)m; bm[word_base + 1] = (uint32_t)(m >> 32); }
-}
-
-// all bits [s, s+len) set?  (bits beyond the trace are stored as zero)
-__device__ __forceinline__ bool bits_all_set(const uint32_t* bm, int s, int len, int nwords) {
-  int pos = s, rem = len;
-  while (rem > 0) {
-    int w = pos >> 5, b = pos & 31;
-    if (w >= nwords) return false;
-    int take = min(32 - b, rem);
-    uint32_t mask = (take == 32) ? 0xffffffffu : ((1u << take) - 1u);
-    if (((bm[w] >> b) & mask) != mask) return false;
-    pos += take; rem -= take;
-  }
-  return true;
-}
-
-// Intersect(min_n) on a bit array (RadiationDetectorDSP `_find_intersect_impl`, the
-// scan of reference src/intersect_maximum.jl:41-56): counts runs of set bits that do
-// not start at sample 0 and are at least min_n long; *first = start of the first one.
-__device__ __forceinline__ void intersect_word(const uint32_t* bm, int w, int nwords, int min_n, int* cnt, int* first) {
-  uint32_t h = bm[w];
-  if (h == 0u) { *cnt = 0; *first = 0x7fffffff; return; }  // no run can start in an empty word (most words of a sparse mask)
-  // a run of min_n >= 64 samples that starts in this word covers the whole next word: a flickering mask (threshold inside the
-  // noise: the t0 trapezoid on a baseline) has several short runs per word and none of them needs a closer look
-  if (min_n >= 64 && (w + 1 >= nwords || bm[w + 1] != 0xffffffffu)) { *cnt = 0; *first = 0x7fffffff; return; }
-  uint32_t prev = (w == 0) ? 1u : (bm[w - 1] >> 31);  // sample -1 counts as "high": initial run excluded
-  uint32_t starts = h & ~((h << 1) | prev);
-  if (min_n >= 2) {  // cheap prune: the sample after a run start must be high too
-    const uint32_t next = (w + 1 < nwords) ? (bm[w + 1] & 1u) : 0u;
-    starts &= (h >> 1) | (next << 31);
-  }
-  int c = 0, f = 0x7fffffff;
-  while (starts) {
-    int b = __ffs(starts) - 1;
-    starts &= starts - 1;
-    int s = 32 * w + b;
-    if (min_n <= 2 || bits_all_set(bm, s + 2, min_n - 2, nwords)) { ++c; f = min(f, s); }
-  }
-  *cnt = c; *first = f;
-}
-// The same scan on the REVERSED trace (get_intracePileUp, reference src/dsp_routines.jl:79):
-// runs that do not touch the last sample n-1, at least min_n long; *last_end = largest end index.
-__device__ __forceinline__ void intersect_word_rev(const uint32_t* bm, int w, int nwords, int n, int min_n, int* cnt, int* last_end) {
-  uint32_t h = bm[w];
-  if (h == 0u) { *cnt = 0; *last_end = -1; return; }
-  uint32_t nextbit;
-  if (32 * w + 32 == n) nextbit = 1u;  // the sample just past the end counts as "high"
-  else nextbit = (w + 1 < nwords) ? (bm[w + 1] & 1u) : 0u;
-  uint32_t hn = (h >> 1) | (nextbit << 31);
-  if ((n >> 5) == w && (n & 31) != 0) hn |= 1u << ((n & 31) - 1);
-  uint32_t ends = h & ~hn;
-  int c = 0, e_best = -1;
-  while (ends) {
-    int b = __ffs(ends) - 1;
-    ends &= ends - 1;
-    int e = 32 * w + b;
-    if (e >= n) continue;
-    int s = e - min_n + 1;
-    if (s >= 0 && (min_n <= 1 || bits_all_set(bm, s, min_n - 1, nwords))) { ++c; e_best = max(e_best, e); }
-  }
-  *cnt = c; *last_end = e_best;
 }
 
 // parabola vertex through three points — reference src/interpolation.jl:8-10

@@ -4,7 +4,8 @@
     extractor and filter at its boundary arguments;
   * the host side of the C ABI (csrc/ldsp_api.hip compiled as plain C++ by g++, launchers stubbed): the complete lowering of
     parameter blocks (ldsp_icpc_check_params) for valid blocks and for blocks with fields corrupted at random (what a
-    binding that mis-lays the struct would send), and the coefficient entry points.
+    binding that mis-lays the struct would send), and the coefficient entry points;
+  * the bit-mask run scans of the kernels (csrc/run_scan.hpp, integer code that g++ compiles as it is) against a bit-by-bit scan.
 A sanitizer report aborts the driver (-fno-sanitize-recover), which fails the test."""
 import ctypes as C
 import os
@@ -104,3 +105,14 @@ def test_host_lowering_under_asan_ubsan(workdir):
     rcs = [int(l.split()[1]) for l in r.stdout.splitlines() if l and l[0].isdigit()]
     assert all(rc == 0 for rc in rcs[:len(valid)])              # what Python lowers, the host lowering accepts
     assert any(rc != 0 for rc in rcs[len(valid):])              # and corrupted blocks are rejected, not executed
+
+
+def test_run_scans_under_asan_ubsan(workdir):
+    """csrc/run_scan.hpp (the Intersect run scans of the kernels, plain integer code) compiled by g++: the word-by-word and the
+    loop-free forms against a bit-by-bit scan — tests/sanitize/run_scan_driver.cpp"""
+    exe = str(workdir / "run_scan_driver")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "legenddsp.jl_amd/csrc")] + SAN +
+                          [os.path.join(ROOT, "tests/sanitize/run_scan_driver.cpp"), "-o", exe])
+    r = subprocess.run([exe], env=ENV, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "run_scan: 0 mismatches" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]

@@ -19,8 +19,6 @@ ldsp.icpc_run(wf, params, ctx, out=out)          # warm-up without stamps
 ctx.set_option("dbg_stamps", buf.data_ptr())
 ldsp.icpc_run(wf, params, ctx, out=out)
 torch.cuda.synchronize()
-names = lean if "lean" in ctx.last_kernel_name() else generic
-print("kernel:", ctx.last_kernel_name())
 ctx.set_option("dbg_stamps", 0)
 s = buf.cpu().numpy()[:, :NW, :].astype(np.float64)     # [block, wave, slot]
 generic = {0: "start", 1: "load + raw sums", 2: "bl reduce + barrier", 3: "blmean, saturation", 4: "shift, tail logs, cumsum scan",
@@ -35,17 +33,20 @@ lean = {0: "start", 1: "load, raw extremes, baseline sums", 2: "per-wave partial
         14: "threshold confirmation, crossings", 15: "estimators (waves 0-2) + barrier", 16: "CZ: Dp, d (+barrier)",
         17: "CZ: flat top + ZAC taps (summed by parts)", 18: "CZ: causal scan + readback", 19: "CZ: anti-causal scan + readback",
         20: "CZ: double cumsum + readback", 21: "CZ: maxima, estimator points", 22: "CZ: collect"}
+names = lean if "lean" in ctx.last_kernel_name() else generic
+print("kernel:", ctx.last_kernel_name())
 ids = sorted(names)
 valid = (s[:, :, ids] > 0).all(axis=(1, 2))
 s = s[valid]
 print(f"{valid.sum()} of {BLOCKS} stamped workgroups complete; cycles per wave (mean over waves and workgroups)")
 life = (s[:, :, ids[-1]].max(axis=1) - s[:, :, ids[0]].min(axis=1)).mean()
 tot = 0.0
-print(f"{'phase':42s} {'mean':>8s} {'wait':>8s} {'share':>7s}")
+print(f"{'phase':42s} {'mean':>8s} {'wait':>8s} {'share':>7s}   arrival of waves 0.. after the first one")
 for a, b in zip(ids[:-1], ids[1:]):
     d = (s[:, :, b] - s[:, :, a]).mean()
     # time the average wave then waits for the slowest one of its workgroup at the end of this phase
     spread = (s[:, :, b].max(axis=1, keepdims=True) - s[:, :, b]).mean()
     tot += d
-    print(f"{names[b]:42s} {d:8.0f} {spread:8.0f} {100 * d / life:6.1f}%")
+    late = (s[:, :, b] - s[:, :, b].min(axis=1, keepdims=True)).mean(axis=0)      # per wave: arrival after the first wave
+    print(f"{names[b]:42s} {d:8.0f} {spread:8.0f} {100 * d / life:6.1f}%   " + " ".join(f"{v:5.0f}" for v in late))
 print(f"{'workgroup lifetime (first start -> last end)':42s} {life:8.0f}")
