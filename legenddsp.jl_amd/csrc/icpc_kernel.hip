@@ -139,10 +139,7 @@ __device__ __forceinline__ float trap_at(const float* T, int k, const TrapDev& t
 // Bt: the estimator's basis table staged in LDS at kernel start (a per-lane read from the
 // parameter block in global memory would put ~2 us of latency on the critical path)
 __device__ __forceinline__ float est_weight(const EstDev& E, const float* Bt, int l, float u) {
-  const float* b = &Bt[l * (LDSP_MAX_EST_DEG + 1)];
-  float w = b[E.deg];
-  for (int j = E.deg - 1; j >= 0; --j) w = fmaf(w, u, b[j]);
-  return w;
+  return dni_weight(E, Bt, l, u);   // qdrift.hpp: the whole coefficient row in one read
 }
 // LSQ-polynomial estimate at position p (index space of a signal of length nsig whose
 // samples are produced by getval(i)); computed redundantly by every wave, lane l

@@ -117,10 +117,7 @@ __device__ __forceinline__ float trap_at(const float* T, int k, const TrapDev& t
   return a * t.inv2 - b * t.inv1;
 }
 __device__ __forceinline__ float est_weight(const EstDev& E, const float* Bt, int l, float u) {
-  const float* b = &Bt[l * (LDSP_MAX_EST_DEG + 1)];
-  float w = b[E.deg];
-  for (int j = E.deg - 1; j >= 0; --j) w = fmaf(w, u, b[j]);
-  return w;
+  return dni_weight(E, Bt, l, u);   // qdrift.hpp: the whole coefficient row in one read
 }
 // window [i0, i0 + npts) and local coordinate u of the LSQ estimate at position p in a signal of nsig samples (A3)
 __device__ __forceinline__ void est_window(const EstDev& E, Pos p, int nsig, int* i0, float* u) {
@@ -847,6 +844,48 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
   }
   __syncthreads();
   STAMP(12); DSTOP(12);
+  // (Placed ahead of the mask scans: candidates and y are final since phase 3, and its chain of three dependent LDS reads overlaps
+  // the scans' instead of standing between their barrier and the crossings.)
+  // Confirmation of the five threshold candidates: imin[q] = first QUAD with a sample at or above threshold q.  Lane q of every
+  // wave finds the sample inside the quad and checks that it is not sample 0 (a run that starts the trace is no crossing) and
+  // that the next tx_mintot - 1 samples stay at or above the threshold; all waves reach the same verdict.  A trace that fails
+  // (a noise spike in front of the pulse, thresholds that do not ascend) runs the general scan: bit-masks of y by ballot, run scan
+  // on the words (src/intersect_maximum.jl:41-56).
+  int p_tx = 0x7fffffff;   // lane q < 5: first confirmed sample of threshold q
+  {
+    const int q = min(lane, 4);
+    const float thrq = e_max * ((q == 0) ? 0.1f : (q == 1) ? 0.5f : (q == 2) ? 0.8f : (q == 3) ? 0.9f : 0.99f);   // = thr_tx[q]
+    const int qd = S.sl->imin[IM_TX0 + q];
+    bool ok = e_max > 0.f;
+    if (ok && qd != 0x7fffffff) {
+      const f4 v = *reinterpret_cast<const f4*>(&S.A[4 * qd]);
+      const int e = (v.x >= thrq) ? 0 : (v.y >= thrq) ? 1 : (v.z >= thrq) ? 2 : 3;
+      p_tx = 4 * qd + e;
+      ok = p_tx >= 1 && p_tx + P.tx_mintot <= L;
+      for (int j = 1; ok && j < P.tx_mintot; ++j) ok = S.A[p_tx + j] >= thrq;
+    }
+    if (__ballot(lane < 5 && !ok) != 0ull) {   // block-uniform
+      __syncthreads();
+      if (tid < 5) S.sl->imin[IM_TX0 + tid] = 0x7fffffff;
+      for (int m = 0; m < SP; ++m) {
+        const float yv = S.A[tid + NT * m];
+#pragma unroll
+        for (int qq = 0; qq < 5; ++qq) {
+          const unsigned long long b = __ballot(yv >= thr_tx[qq]);
+          if (lane == 0) *reinterpret_cast<unsigned long long*>(&S.bm[(M_FB + qq) * NWORDS + (NT >> 5) * m + 2 * wave]) = b;
+        }
+      }
+      __syncthreads();
+      for (int j = tid; j < 5 * NWORDS; j += NT) {
+        const int qq = j / NWORDS, wd = j % NWORDS;
+        int c, f;
+        intersect_word(S.bm + (M_FB + qq) * NWORDS, wd, NWORDS, P.tx_mintot, &c, &f);
+        if (c) atomicMin(&S.sl->imin[IM_TX0 + qq], f);
+      }
+      __syncthreads();
+      p_tx = S.sl->imin[IM_TX0 + q];
+    }
+  }
   // Intersect scans on the bit-masks (thread <-> word): t0, inverted t0, in-trace pile-up.  Every word a thread's scans can need is
   // read first (one wait instead of a dependent LDS round trip per word), and the run tests are loop-free (intersect_pre /
   // intersect_rev_pre); run lengths beyond their windows take the word-by-word forms.
@@ -917,50 +956,11 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
     S.outv[C_e_10410] = ford_inv(S.sl->fmx[FX_F0]); S.outv[C_e_535] = ford_inv(S.sl->fmx[FX_F1]); S.outv[C_e_313] = ford_inv(S.sl->fmx[FX_F2]);
     S.outv[C_e_10410_inv] = ford_inv(S.sl->fmx[FX_F0I]); S.outv[C_e_313_inv] = ford_inv(S.sl->fmx[FX_F2I]);   // trap(-y) = -trap(y)  (dsp_icpc.jl:199-204)
   }
-  // Confirmation of the five threshold candidates: imin[q] = first QUAD with a sample at or above threshold q.  Lane q of every
-  // wave finds the sample inside the quad and checks that it is not sample 0 (a run that starts the trace is no crossing) and
-  // that the next tx_mintot - 1 samples stay at or above the threshold; all waves reach the same verdict.  A trace that fails
-  // (a noise spike in front of the pulse, thresholds that do not ascend) runs the general scan: bit-masks of y by ballot, run scan
-  // on the words (src/intersect_maximum.jl:41-56).
-  int p_tx = 0x7fffffff;   // lane q < 5: first confirmed sample of threshold q
-  {
-    const int q = min(lane, 4);
-    const float thrq = e_max * ((q == 0) ? 0.1f : (q == 1) ? 0.5f : (q == 2) ? 0.8f : (q == 3) ? 0.9f : 0.99f);   // = thr_tx[q]
-    const int qd = S.sl->imin[IM_TX0 + q];
-    bool ok = e_max > 0.f;
-    if (ok && qd != 0x7fffffff) {
-      const f4 v = *reinterpret_cast<const f4*>(&S.A[4 * qd]);
-      const int e = (v.x >= thrq) ? 0 : (v.y >= thrq) ? 1 : (v.z >= thrq) ? 2 : 3;
-      p_tx = 4 * qd + e;
-      ok = p_tx >= 1 && p_tx + P.tx_mintot <= L;
-      for (int j = 1; ok && j < P.tx_mintot; ++j) ok = S.A[p_tx + j] >= thrq;
-    }
-    if (__ballot(lane < 5 && !ok) != 0ull) {   // block-uniform
-      __syncthreads();
-      if (tid < 5) S.sl->imin[IM_TX0 + tid] = 0x7fffffff;
-      for (int m = 0; m < SP; ++m) {
-        const float yv = S.A[tid + NT * m];
-#pragma unroll
-        for (int qq = 0; qq < 5; ++qq) {
-          const unsigned long long b = __ballot(yv >= thr_tx[qq]);
-          if (lane == 0) *reinterpret_cast<unsigned long long*>(&S.bm[(M_FB + qq) * NWORDS + (NT >> 5) * m + 2 * wave]) = b;
-        }
-      }
-      __syncthreads();
-      for (int j = tid; j < 5 * NWORDS; j += NT) {
-        const int qq = j / NWORDS, wd = j % NWORDS;
-        int c, f;
-        intersect_word(S.bm + (M_FB + qq) * NWORDS, wd, NWORDS, P.tx_mintot, &c, &f);
-        if (c) atomicMin(&S.sl->imin[IM_TX0 + qq], f);
-      }
-      __syncthreads();
-      p_tx = S.sl->imin[IM_TX0 + q];
-    }
-  }
   // crossing positions (sample units, split int + frac); NaN -> 0 us (dsp_routines.jl:24,41).  Seven interpolations, one per
   // lane (q < 5: threshold q of y; 5: t0; 6: inverted t0), evaluated by every wave and handed out by readlane.
-  Pos ptx1, ptx2, pt0;
-  {
+  Pos ptx1 = {0, 0.f}, ptx2 = {0, 0.f}, pt0 = {0, 0.f};
+  constexpr int W_CZWIN = 4 % NW;   // the wave that places the CUSP / ZAC estimator windows
+  if (wave <= 2 || wave == W_CZWIN || wave == NW - 1) {   // the waves that use a position (estimators, windows) or store the times
     const int q = min(lane, 6);
     const int p = (q < 5) ? p_tx : S.sl->imin[q];
     const bool has = (q < 5) ? p != 0x7fffffff : S.sl->isum[IS_T0 + q - 5] > 0;
@@ -1014,6 +1014,8 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
         v = wave_total(t);
       }
       if (lane == 0) eslot[0] = v;
+    }
+    if (wave == W_CZWIN) {
       // windows of the CUSP / ZAC estimates (t50 + flt_length/2, dsp_icpc.jl:170,177) for the last phase
       const int nout_c = L - P.cusp.Lf + 1, nout_z = L - P.zac.Lf + 1;
       if (lane == 0) { S.misc[12] = 0.f; S.misc[13] = 0.f; }
@@ -1064,6 +1066,7 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       if (interior) v = extrema3points(em, e0, ep);
       if (lane < 12 && d == -1) S.outv[f == 0 ? C_a_sg : f == 1 ? C_a_60 : f == 2 ? C_a_100 : C_a_raw] = v;
     }
+    STAMP(15); DSTOP(15);
     __syncthreads();
     if (tid == 0) {
       S.outv[C_e_trap] = eslot[0];
@@ -1071,7 +1074,6 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       S.outv[C_lq] = eslot[2];
     }
   }
-  STAMP(15); DSTOP(15);
 
   // ------------------------------------------------------------------------------------ phase 7: CUSP / ZAC (dsp_icpc.jl:167-178)
   // Closed form (CUSP / ZAC): with d[i] = y[i] - a*y[i-1],

@@ -21,12 +21,24 @@ __device__ __forceinline__ void dni_window(const EstDev& E, int ip, float fp, in
   *i0 = a;
   *u = ((float)(ip - a) + fp - E.c) * E.s_inv;
 }
-__device__ __forceinline__ float dni_weight(const EstDev& E, const float* Bt, int l, float u) {
-  const float* b = &Bt[l * (LDSP_MAX_EST_DEG + 1)];
-  float w = b[E.deg];
-  for (int j = E.deg - 1; j >= 0; --j) w = fmaf(w, u, b[j]);
+// Weight of window point l at local coordinate u: the polynomial sum_j B[l][j] u^j.  A row of the basis table holds
+// LDSP_MAX_EST_DEG + 1 coefficients, zero above the estimator's degree (and for points beyond its window): all of them are read
+// together (one wait; a Horner loop over the degree with a read per step was a chain of dependent LDS round trips) and the
+// Horner chain starts from zero — fma(0, u, b[deg]) = b[deg], the same values as a chain that starts at the degree.
+struct DniRow { float b[LDSP_MAX_EST_DEG + 1]; };
+__device__ __forceinline__ DniRow dni_row(const float* Bt, int l) {
+  DniRow r;
+#pragma unroll
+  for (int j = 0; j <= LDSP_MAX_EST_DEG; ++j) r.b[j] = Bt[l * (LDSP_MAX_EST_DEG + 1) + j];
+  return r;
+}
+__device__ __forceinline__ float dni_poly(const DniRow& r, float u) {
+  float w = 0.f;
+#pragma unroll
+  for (int j = LDSP_MAX_EST_DEG; j >= 0; --j) w = fmaf(w, u, r.b[j]);
   return w;
 }
+__device__ __forceinline__ float dni_weight(const EstDev& E, const float* Bt, int l, float u) { return dni_poly(dni_row(Bt, l), u); }
 
 // Y: the trace in LDS (nsig samples); Bt: the estimator's basis table in LDS; (ip[k], fp[k]): the three positions t, t + d1, t + d2
 // in samples.  Must be called by all 64 lanes of a wave.  NaN if the trace is shorter than the estimator window.
@@ -46,6 +58,7 @@ __device__ __forceinline__ float qdrift_wave(const EstDev& E, const float* Bt, c
   const int ch = (span + 63) / 64;                                       // consecutive samples per lane
   constexpr int CH = 8;
   float t = 0.f;
+  const DniRow row = dni_row(Bt, lane);   // (64 rows in the table; rows beyond the window are zero)
   if (scratch && ch <= CH) {   // (wave-uniform)
     float v[CH];
 #pragma unroll
@@ -66,7 +79,7 @@ __device__ __forceinline__ float qdrift_wave(const EstDev& E, const float* Bt, c
     for (int k = 0; k < 3; ++k) {
       const int i = (lane < E.npts) ? i0[k] + lane : ref;
       const float d = (i > ref) ? scratch[i - ref - 1] : 0.f;
-      if (lane < E.npts) t = fmaf(dni_weight(E, Bt, lane, u[k]) * ((k == 1) ? -2.f : 1.f), d, t);   // E1 - 2 E2 + E3
+      if (lane < E.npts) t = fmaf(dni_poly(row, u[k]) * ((k == 1) ? -2.f : 1.f), d, t);   // E1 - 2 E2 + E3
     }
   } else {
     float loc = 0.f;
@@ -83,7 +96,7 @@ __device__ __forceinline__ float qdrift_wave(const EstDev& E, const float* Bt, c
       float d = __shfl(excl, c);
       for (int j = 0; j <= jj; ++j) d += Y[ref + 1 + c * ch + j];
       if (i <= ref) d = 0.f;
-      if (lane < E.npts) t = fmaf(dni_weight(E, Bt, lane, u[k]) * ((k == 1) ? -2.f : 1.f), d, t);   // E1 - 2 E2 + E3
+      if (lane < E.npts) t = fmaf(dni_poly(row, u[k]) * ((k == 1) ? -2.f : 1.f), d, t);   // E1 - 2 E2 + E3
     }
   }
   LDSP_DPP_GROUP1("v_add_f32_dpp", t);

@@ -30,7 +30,7 @@ lean = {0: "start", 1: "load, raw extremes, baseline sums", 2: "per-wave partial
         4: "pz offsets (wave 0) + barrier, pole-zero", 5: "y -> LDS, wvf maxima + barrier", 6: "SG pass (S4, packed)", 7: "SG reductions",
         8: "LS pass: sg50 crossing, in-trace mask", 9: "T scan (wave 0) + T -> LDS + barriers", 10: "sweep A (t0 masks)",
         11: "sweep B (4 trapezoids)", 12: "sweep reductions + barrier", 13: "run scans on the masks + barrier",
-        14: "threshold confirmation, crossings", 15: "estimators (waves 0-2) + barrier", 16: "CZ: Dp, d (+barrier)",
+        14: "threshold confirmation, crossings", 15: "estimators, parabolas (waves 0-3), to the barrier", 16: "barrier, CZ: Dp, d (+barrier)",
         17: "CZ: flat top + ZAC taps (summed by parts)", 18: "CZ: causal scan + readback", 19: "CZ: anti-causal scan + readback",
         20: "CZ: double cumsum + readback", 21: "CZ: maxima, estimator points", 22: "CZ: collect"}
 names = lean if "lean" in ctx.last_kernel_name() else generic
