@@ -313,6 +313,11 @@ int ldsp_sg_grid_run(ldsp_ctx* ctx, const float* wf, int64_t n, const ldsp_trapg
 int ldsp_icpc_pz_trap_run(ldsp_ctx* ctx, const float* wf, int64_t n,
                           const ldsp_icpc_params* p, float* blmean,
                           float* e_10410);
+/* The same on uint16 ADC counts ([n][L]), converted while loading: 2L instead of 4L bytes per trace for this HBM-bound
+ * sub-chain; results bit-identical to the float32 entry (every uint16 is exact in float32). */
+int ldsp_icpc_pz_trap_run_u16(ldsp_ctx* ctx, const uint16_t* wf, int64_t n,
+                              const ldsp_icpc_params* p, float* blmean,
+                              float* e_10410);
 
 /* dsp_sipm(data, config, pars_optimization)       src/dsp_sipm.jl:47-158 */
 int ldsp_sipm_run(ldsp_ctx* ctx, const float* wf, int64_t n,

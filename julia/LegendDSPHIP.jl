@@ -358,6 +358,16 @@ function icpc_pz_trap(wvfs::GPUWaveforms, config::DSPConfig, τ, pars_filter::Pr
                 ctx.h, devptr(x), n, Ref(p), devptr(blmean), devptr(e10410)))
     (blmean = blmean, e_10410 = e10410)
 end
+"The same on UInt16 ADC counts ([L, n] device array; converted by the kernel as it loads them: ldsp_icpc_pz_trap_run_u16)"
+function icpc_pz_trap(x::ROCArray{UInt16,2}, t_first, dt, config::DSPConfig, τ, pars_filter::PropDict; ctx::LdspCtx = default_ctx())
+    L, n = size(x)
+    p = lower_icpc(config, τ, pars_filter, L, t_first, dt)
+    blmean, e10410 = ROCVector{Float32}(undef, n), ROCVector{Float32}(undef, n)
+    check(ccall((:ldsp_icpc_pz_trap_run_u16, libldsp), Cint,
+                (Ptr{Cvoid}, Ptr{UInt16}, Int64, Ref{LdspIcpcParams}, Ptr{Float32}, Ptr{Float32}),
+                ctx.h, devptr(x), n, Ref(p), devptr(blmean), devptr(e10410)))
+    (blmean = blmean, e_10410 = e10410)
+end
 
 # one trigger group of dsp_sipm: count + four slabs of `cap` entries per trace
 struct TrigBuffers

@@ -61,6 +61,7 @@ def _declare(lib):
     sig("ldsp_icpc_check_params", [_VOIDP])
     sig("ldsp_icpc_run", [_VOIDP, _VOIDP, _I64, C.POINTER(_abi.IcpcParams), C.POINTER(_abi.IcpcOut)])
     sig("ldsp_icpc_pz_trap_run", [_VOIDP, _VOIDP, _I64, C.POINTER(_abi.IcpcParams), _VOIDP, _VOIDP])
+    sig("ldsp_icpc_pz_trap_run_u16", [_VOIDP, _VOIDP, _I64, C.POINTER(_abi.IcpcParams), _VOIDP, _VOIDP])
     sig("ldsp_trap_grid_run", [_VOIDP, _VOIDP, _I64, C.POINTER(_abi.TrapGridParams), _I32, _VOIDP, _VOIDP, _VOIDP])
     sig("ldsp_sg_grid_run", [_VOIDP, _VOIDP, _I64, C.POINTER(_abi.TrapGridParams), C.POINTER(_abi.Trap), _DBL, _DBL, _I32, _VOIDP, _I32,
                               _VOIDP, _VOIDP, _VOIDP, _VOIDP, _VOIDP, _VOIDP, _VOIDP])
@@ -106,7 +107,7 @@ DECLARED_SYMBOLS = [
     "ldsp_abi_version", "ldsp_abi_sizeof", "ldsp_ctx_create", "ldsp_ctx_destroy", "ldsp_ctx_set_stream",
     "ldsp_ctx_use_own_stream",
     "ldsp_ctx_synchronize", "ldsp_last_error_string", "ldsp_ctx_set_option", "ldsp_ctx_enable_timing",
-    "ldsp_ctx_last_kernel_ms", "ldsp_ctx_last_stage_ms", "ldsp_ctx_last_kernel_name", "ldsp_icpc_check_params", "ldsp_icpc_run", "ldsp_icpc_pz_trap_run", "ldsp_trap_grid_run", "ldsp_fir_grid_run", "ldsp_sg_grid_run", "ldsp_sipm_run", "ldsp_sipm_run_u16",
+    "ldsp_ctx_last_kernel_ms", "ldsp_ctx_last_stage_ms", "ldsp_ctx_last_kernel_name", "ldsp_icpc_check_params", "ldsp_icpc_run", "ldsp_icpc_pz_trap_run", "ldsp_icpc_pz_trap_run_u16", "ldsp_trap_grid_run", "ldsp_fir_grid_run", "ldsp_sg_grid_run", "ldsp_sipm_run", "ldsp_sipm_run_u16",
     "ldsp_rdfilt_invcr", "ldsp_rdfilt_integrator", "ldsp_rdfilt_trap", "ldsp_rdfilt_fir",
     "ldsp_rdfilt_derivative", "ldsp_rdfilt_haar", "ldsp_rdfilt_moving_window",
     "ldsp_rdfilt_moving_window_multi", "ldsp_rdfilt_affine", "ldsp_cusp_coeffs", "ldsp_zac_coeffs",

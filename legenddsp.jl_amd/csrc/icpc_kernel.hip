@@ -1576,10 +1576,12 @@ pz_trap_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, flo
   double* wsum = part + 2 * R * NW;                           // [NW]
   float* fred = reinterpret_cast<float*>(wsum + NW);          // [NW]
   const float* w = wf + (size_t)blockIdx.x * (size_t)L;
+  const uint16_t* w16 = reinterpret_cast<const uint16_t*>(wf) + (size_t)blockIdx.x * (size_t)L;   // (in_u16)
   float x[R][4];
-  load_trace_s4<NT, R, FULL>(w, L, tid, x);
+  if (P.in_u16) load_trace_s4_u16<NT, R, FULL>(w16, L, tid, x);
+  else load_trace_s4<NT, R, FULL>(w, L, tid, x);
   // baseline mean exactly as icpc_kernel forms it (same pivot, same summation order)
-  const float pv_bl = w[P.bl.from];
+  const float pv_bl = P.in_u16 ? (float)w16[P.bl.from] : w[P.bl.from];
   WinAccF bl = {0, 0, 0};
 #pragma unroll
   for (int r = 0; r < R; ++r) {

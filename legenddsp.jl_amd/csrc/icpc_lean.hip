@@ -1438,11 +1438,20 @@ pz_trap_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp
   float* scn = part + 2 * R * NW;                          // [3][R*NW]: what wave 0 makes of the wave-row totals (row_prefix_f64)
   float* wred = scn + 3 * R * NW;                          // [2][NW]: s1 partials, trapezoid maxima
   const float* w = wf + (size_t)blockIdx.x * (size_t)L;
+  const uint16_t* w16 = reinterpret_cast<const uint16_t*>(wf) + (size_t)blockIdx.x * (size_t)L;   // (in_u16: ADC counts, converted here)
   f4 x[R];
+  if (P.in_u16) {   // (block-uniform)
 #pragma unroll
-  for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
+    for (int r = 0; r < R; ++r) {
+      const uint2 q = *reinterpret_cast<const uint2*>(w16 + 4 * (tid + NT * r));
+      x[r] = (f4){(float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16)};
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
+  }
   asm volatile("; LDSP_PHASE 1");
-  const float pv_bl = w[P.bl.from];
+  const float pv_bl = P.in_u16 ? (float)w16[P.bl.from] : w[P.bl.from];
   const uint32_t cls_bl = P.rowcls[0][wave];
   {   // baseline sum: the s1 chain of icpc_lean_kernel's phase 1
     f2 a1 = splat(0.f);

@@ -500,13 +500,13 @@ int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_
   return LDSP_OK;
 }
 
-int ldsp_icpc_pz_trap_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_params* p, float* blmean, float* e_10410) {
+static int pz_trap_run_impl(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_params* p, float* blmean, float* e_10410, bool in_u16) {
   if (!c || !p || !blmean || !e_10410) return fail(LDSP_ERR_INVALID_ARG, "ldsp_icpc_pz_trap_run: NULL argument");
   if (n < 0 || n > 0x7fffffffLL) return fail(LDSP_ERR_INVALID_ARG, "n = %lld out of range", (long long)n);
   if (n == 0) return LDSP_OK;
   if (!wf) return fail(LDSP_ERR_INVALID_ARG, "waveform pointer is NULL");
   ldsp_device_guard guard(c->device);
-  int rc = prepare_icpc(c, p);
+  int rc = prepare_icpc(c, p, in_u16);   // (the kernels read in_u16 from the parameter block)
   if (rc) return rc;
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   const int nt_pz = c->icpc_host.R == 2 ? 512 : c->icpc_host.NT;   // pz_trap_kernel keeps 16 samples per thread
@@ -519,6 +519,12 @@ int ldsp_icpc_pz_trap_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_ic
   }
   if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
   return LDSP_OK;
+}
+int ldsp_icpc_pz_trap_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_params* p, float* blmean, float* e_10410) {
+  return pz_trap_run_impl(c, wf, n, p, blmean, e_10410, false);
+}
+int ldsp_icpc_pz_trap_run_u16(ldsp_ctx* c, const uint16_t* wf, int64_t n, const ldsp_icpc_params* p, float* blmean, float* e_10410) {
+  return pz_trap_run_impl(c, reinterpret_cast<const float*>(wf), n, p, blmean, e_10410, true);
 }
 
 int ldsp_trap_grid_run(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_trapgrid_params* p, int32_t G, const ldsp_trap* traps,

@@ -99,21 +99,23 @@ def icpc_run(wf: torch.Tensor, params: _abi.IcpcParams, ctx: _lib.Context = None
 
 
 def icpc_pz_trap_run(wf: torch.Tensor, params: _abi.IcpcParams, ctx: _lib.Context = None, out: torch.Tensor = None):
-    """BASELINE config 2 sub-chain (blmean, e_10410) — `ldsp_icpc_pz_trap_run`. Returns a [2, n] tensor."""
+    """BASELINE config 2 sub-chain (blmean, e_10410) — `ldsp_icpc_pz_trap_run`. Returns a [2, n] tensor.
+    A uint16 tensor (ADC counts) goes to `ldsp_icpc_pz_trap_run_u16` as it is: converted while loading, half the bytes."""
     if not wf.is_cuda:
         raise _lib.LdspError(-103, "needs a device-resident waveform tensor (no CPU fallback)")
     ctx = ctx or _lib.default_context(wf.device.index)
     n, L = wf.shape
     if L != params.L:
         raise ValueError(f"waveform length {L} != params.L {params.L}")
-    wf = _as_device_f32(wf, wf.device)
+    in_u16 = wf.dtype == torch.uint16
+    wf = wf.contiguous() if in_u16 else _as_device_f32(wf, wf.device)
     if out is None:
         out = torch.empty((2, n), dtype=torch.float32, device=wf.device)
     if out.shape != (2, n) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != wf.device:
         raise ValueError(f"out must be a contiguous float32 [2, {n}] tensor on the waveforms' device")
     ctx.bind_stream()
-    _lib.check(_lib.lib().ldsp_icpc_pz_trap_run(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params),
-                                                C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr())))
+    run = _lib.lib().ldsp_icpc_pz_trap_run_u16 if in_u16 else _lib.lib().ldsp_icpc_pz_trap_run
+    _lib.check(run(ctx.handle, C.c_void_p(wf.data_ptr()), n, C.byref(params), C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr())))
     return out
 
 

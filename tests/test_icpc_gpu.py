@@ -247,3 +247,20 @@ def test_uint16_adc_counts_are_converted_by_the_kernel(params, generic, two_kern
         ctx.set_option("two_kernel", 0)
     for c in ldsp._abi.ICPC_COLS:
         assert np.array_equal(a[c], b[c], equal_nan=True), c
+
+
+@pytest.mark.parametrize("length,dt", [(8192, 16.0), (8000, 16.0), (4096, 32.0)])
+def test_pz_trap_subchain_on_uint16_adc_counts(length, dt):
+    """ldsp_icpc_pz_trap_run_u16: uint16 ADC counts give blmean / e_10410 of the same values passed as float32, bit for bit
+    (lean kernel at 8192 and 4096 samples, generic kernel at 8000), and they are the fused chain's columns."""
+    cfg = ldsp.plumbing_icpc_config_4096() if length == 4096 else ldsp.reference_test_icpc_config()
+    p = ldsp.lower_icpc(cfg, 500 * ldsp.us, {}, length, 0.0, dt)
+    wf = ldsp.synth.hpge_batch(192, 8192, device="cuda", seed=43).round().clamp(0, 65535)
+    wf = (wf[:, ::2] if dt != 16.0 else wf[:, :length]).contiguous()
+    wf16 = wf.to(torch.uint16)
+    assert torch.equal(wf16.to(torch.float32), wf)
+    a = ldsp.icpc_pz_trap_run(wf, p).cpu().numpy()
+    b = ldsp.icpc_pz_trap_run(wf16, p).cpu().numpy()
+    assert np.array_equal(a, b)
+    full = ldsp.table_columns(ldsp.icpc_run(wf16, p))
+    assert np.array_equal(b[0], full["blmean"].cpu().numpy()) and np.array_equal(b[1], full["e_10410"].cpu().numpy())

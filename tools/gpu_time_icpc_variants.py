@@ -29,3 +29,13 @@ def timed(fn):
 t_a = timed(lambda: ldsp.icpc_run(w16, p, ctx))
 t_b = timed(lambda: ldsp.icpc_run(w16.to(torch.float32), p, ctx))
 print(f"uint16 input, converted while loading: {t_a:.3f} ms -> {n / t_a * 1e3 / 1e6:.2f} M waveforms/s;  cast pass + float32 kernel: {t_b:.3f} ms -> {n / t_b * 1e3 / 1e6:.2f} M waveforms/s")
+# BASELINE config 2 (pole-zero + trapezoid) on float32 and on uint16 input, at a batch that does not fit the caches
+n2 = int(sys.argv[2]) if len(sys.argv) > 2 else 524288
+wf2 = ldsp.synth.hpge_batch(65536, L, device="cuda").round().clamp(0, 65535).repeat(n2 // 65536, 1)
+w2_16 = wf2.to(torch.uint16)
+out2 = torch.empty((2, n2), dtype=torch.float32, device="cuda")
+for name, x, bpt in (("float32", wf2, 4 * L + 8), ("uint16", w2_16, 2 * L + 8)):
+    ldsp.icpc_pz_trap_run(x, p, ctx, out=out2); torch.cuda.synchronize()
+    ms = min((ldsp.icpc_pz_trap_run(x, p, ctx, out=out2), ctx.last_kernel_ms())[1] for _ in range(5))
+    print(f"pole-zero + trapezoid, {name} input, {n2} traces: {ctx.last_kernel_name()} {ms:.3f} ms -> {n2 / ms * 1e3 / 1e6:.1f} M waveforms/s, "
+          f"{n2 * bpt / ms * 1e3 / 1e12:.2f} TB/s = {n2 * bpt / ms * 1e3 / 8e12 * 100:.0f} % of 8 TB/s ({bpt} B per trace)")
