@@ -1425,7 +1425,9 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
 // BASELINE config 2: blmean -> shift -> InvCR -> Trap(10 us, 4 us) -> maximum (reference src/dsp_icpc.jl:102-105,119-120,
 // 147-148).  The same statements as icpc_lean_kernel, nothing else: blmean and e_10410 come out bit-identical to the fused
 // chain's columns (tests/test_baseline_sizes_gpu.py).  One trace-sized LDS array (T): four workgroups per CU.
-template <int NT>
+// U16: the traces are uint16 ADC counts, converted as they are loaded — a template parameter, not the block's in_u16 field: a
+// scalar load + branch in front of the trace loads of this memory-bound kernel cost 4 % (5.68 -> 5.90 ms per 10^6 traces).
+template <int NT, bool U16>
 __global__ void __launch_bounds__(NT, 8)
 pz_trap_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float* __restrict__ o_blmean, float* __restrict__ o_e10410) {
   constexpr int NW = NT / 64, Lp = NT * SP, L = Lp;
@@ -1440,7 +1442,7 @@ pz_trap_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp
   const float* w = wf + (size_t)blockIdx.x * (size_t)L;
   const uint16_t* w16 = reinterpret_cast<const uint16_t*>(wf) + (size_t)blockIdx.x * (size_t)L;   // (in_u16: ADC counts, converted here)
   f4 x[R];
-  if (P.in_u16) {   // (block-uniform)
+  if constexpr (U16) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const uint2 q = *reinterpret_cast<const uint2*>(w16 + 4 * (tid + NT * r));
@@ -1451,7 +1453,7 @@ pz_trap_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp
     for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
   }
   asm volatile("; LDSP_PHASE 1");
-  const float pv_bl = P.in_u16 ? (float)w16[P.bl.from] : w[P.bl.from];
+  const float pv_bl = U16 ? (float)w16[P.bl.from] : w[P.bl.from];
   const uint32_t cls_bl = P.rowcls[0][wave];
   {   // baseline sum: the s1 chain of icpc_lean_kernel's phase 1
     f2 a1 = splat(0.f);
@@ -1569,14 +1571,18 @@ pz_trap_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp
   }
 }
 
-template <int NT>
-static hipError_t launch_pz_t(const float* wf, int64_t n, const IcpcDev* dP, float* a, float* b, hipStream_t st) {
+template <int NT, bool U16>
+static hipError_t launch_pz_tu(const float* wf, int64_t n, const IcpcDev* dP, float* a, float* b, hipStream_t st) {
   constexpr int NW = NT / 64;
   const size_t smem = (size_t)(NT * SP + 64 + 2 * NT + 5 * R * NW + 2 * NW) * 4 + 16;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pz_trap_lean_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pz_trap_lean_kernel<NT, U16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((pz_trap_lean_kernel<NT>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, a, b);
+  hipLaunchKernelGGL((pz_trap_lean_kernel<NT, U16>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, a, b);
   return hipGetLastError();
+}
+template <int NT>
+static hipError_t launch_pz_t(const float* wf, int64_t n, bool u16, const IcpcDev* dP, float* a, float* b, hipStream_t st) {
+  return u16 ? launch_pz_tu<NT, true>(wf, n, dP, a, b, st) : launch_pz_tu<NT, false>(wf, n, dP, a, b, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1605,15 +1611,15 @@ size_t icpc_lean_smem_bytes(int NT, int Lf) {
   }
 }
 
-hipError_t launch_pz_trap_lean(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st) {
+hipError_t launch_pz_trap_lean(const float* wf, int64_t n, int NT, bool u16, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st) {
   switch (NT) {
 #ifndef LDSP_DEV_512
-    case 64: return lean::launch_pz_t<64>(wf, n, dP, blmean, e10410, st);
-    case 128: return lean::launch_pz_t<128>(wf, n, dP, blmean, e10410, st);
-    case 256: return lean::launch_pz_t<256>(wf, n, dP, blmean, e10410, st);
-    case 1024: return lean::launch_pz_t<1024>(wf, n, dP, blmean, e10410, st);
+    case 64: return lean::launch_pz_t<64>(wf, n, u16, dP, blmean, e10410, st);
+    case 128: return lean::launch_pz_t<128>(wf, n, u16, dP, blmean, e10410, st);
+    case 256: return lean::launch_pz_t<256>(wf, n, u16, dP, blmean, e10410, st);
+    case 1024: return lean::launch_pz_t<1024>(wf, n, u16, dP, blmean, e10410, st);
 #endif
-    case 512: return lean::launch_pz_t<512>(wf, n, dP, blmean, e10410, st);
+    case 512: return lean::launch_pz_t<512>(wf, n, u16, dP, blmean, e10410, st);
     default: return hipErrorInvalidValue;
   }
 }

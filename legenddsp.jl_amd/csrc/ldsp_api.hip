@@ -22,7 +22,7 @@ hipError_t launch_icpc(const float* wf, int64_t n, int NT, int R, bool full, con
 hipError_t launch_icpc_lean(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, const IcpcDev* dP, const IcpcOutDev& out,
                             const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st);
 size_t icpc_lean_smem_bytes(int NT, int Lf);
-hipError_t launch_pz_trap_lean(const float* wf, int64_t n, int NT, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
+hipError_t launch_pz_trap_lean(const float* wf, int64_t n, int NT, bool u16, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 size_t icpc_smem_bytes(int NT);
 hipError_t launch_trap_grid(const float* wf, int64_t n, int NT, bool full, const TrapGridDev* dP, float* out, hipStream_t st);
@@ -511,7 +511,7 @@ static int pz_trap_run_impl(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   const int nt_pz = c->icpc_host.R == 2 ? 512 : c->icpc_host.NT;   // pz_trap_kernel keeps 16 samples per thread
   if (icpc_lean_applies(c)) {
-    HIP_TRY(launch_pz_trap_lean(wf, n, c->icpc_host.NT, c->d_icpc, blmean, e_10410, c->stream));
+    HIP_TRY(launch_pz_trap_lean(wf, n, c->icpc_host.NT, in_u16, c->d_icpc, blmean, e_10410, c->stream));
     c->last_kernel = "lean::pz_trap_lean_kernel";
   } else {
     HIP_TRY(launch_pz_trap(wf, n, nt_pz, c->icpc_host.L == 16 * nt_pz, c->d_icpc, blmean, e_10410, c->stream));

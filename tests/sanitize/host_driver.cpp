@@ -17,7 +17,7 @@ hipError_t launch_icpc(const float*, int64_t, int, int, bool, const IcpcDev*, fl
                        hipStream_t, hipEvent_t, int*) { return hipErrorNotSupported; }
 hipError_t launch_icpc_lean(const float*, int64_t, int, int, bool, const IcpcDev*, const IcpcOutDev&, const float*, float, int, hipStream_t) { return hipErrorNotSupported; }
 size_t icpc_lean_smem_bytes(int NT, int Lf) { return (size_t)(2 * NT * 16 + Lf) * 4; }
-hipError_t launch_pz_trap_lean(const float*, int64_t, int, const IcpcDev*, float*, float*, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_pz_trap_lean(const float*, int64_t, int, bool, const IcpcDev*, float*, float*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_pz_trap(const float*, int64_t, int, bool, const IcpcDev*, float*, float*, hipStream_t) { return hipErrorNotSupported; }
 size_t icpc_smem_bytes(int NT) { return (size_t)NT * 16 * 8; }
 hipError_t launch_trap_grid(const float*, int64_t, int, bool, const TrapGridDev*, float*, hipStream_t) { return hipErrorNotSupported; }
