@@ -88,30 +88,32 @@ LDSP_RS unsigned long long runs_from(unsigned long long x, int n) {
   for (int have = 1; have < n;) { const int st = min(have, n - have); x &= x >> st; have += st; }
   return x;
 }
-// Intersect(min_n), min_n <= 97: runs that start in word w (not at sample 0) and last min_n samples; count and first start
-LDSP_RS void intersect_pre(uint32_t hm1, uint32_t h, uint32_t h1, uint32_t h2, uint32_t h3, int w, int min_n, int* cnt, int* first) {
-  *cnt = 0; *first = 0x7fffffff;
+// Intersect(min_n), min_n <= 97: the starts (bits of word w) of the runs that begin in word w — not at sample 0 — and last min_n samples
+LDSP_RS uint32_t intersect_pre_mask(uint32_t hm1, uint32_t h, uint32_t h1, uint32_t h2, uint32_t h3, int w, int min_n) {
   const uint32_t prev = (w == 0) ? 1u : (hm1 >> 31);   // sample -1 counts as "high": a run that starts the trace is no crossing
   const uint32_t starts = h & ~((h << 1) | prev);
-  if (starts == 0u) return;
+  if (starts == 0u) return 0u;
   const unsigned long long lo = (unsigned long long)h | ((unsigned long long)h1 << 32);
-  if (min_n <= 32) {
-    const uint32_t ok = starts & (uint32_t)runs_from(lo, min_n);
-    if (ok) { *cnt = __popc(ok); *first = 32 * w + __ffs(ok) - 1; }
-  } else {   // a run of more than 32 samples leaves the word: only the last start of the word can be one
-    const int b = 31 - __clz(starts);
-    const unsigned long long hi = (unsigned long long)h2 | ((unsigned long long)h3 << 32);
-    const unsigned long long l2 = b ? (lo >> b) | (hi << (64 - b)) : lo, u2 = hi >> b;   // the 128-bit window from the start on
-    bool all;
-    if (min_n <= 64) {
-      const unsigned long long m = (min_n == 64) ? ~0ull : ((1ull << min_n) - 1ull);
-      all = (l2 & m) == m;
-    } else {
-      const unsigned long long m = (1ull << (min_n - 64)) - 1ull;
-      all = l2 == ~0ull && (u2 & m) == m;
-    }
-    if (all) { *cnt = 1; *first = 32 * w + b; }
+  if (min_n <= 32) return starts & (uint32_t)runs_from(lo, min_n);
+  // a run of more than 32 samples leaves the word: only the last start of the word can be one
+  const int b = 31 - __clz(starts);
+  const unsigned long long hi = (unsigned long long)h2 | ((unsigned long long)h3 << 32);
+  const unsigned long long l2 = b ? (lo >> b) | (hi << (64 - b)) : lo, u2 = hi >> b;   // the 128-bit window from the start on
+  bool all;
+  if (min_n <= 64) {
+    const unsigned long long m = (min_n == 64) ? ~0ull : ((1ull << min_n) - 1ull);
+    all = (l2 & m) == m;
+  } else {
+    const unsigned long long m = (1ull << (min_n - 64)) - 1ull;
+    all = l2 == ~0ull && (u2 & m) == m;
   }
+  return all ? (1u << b) : 0u;
+}
+// ... as count and first start
+LDSP_RS void intersect_pre(uint32_t hm1, uint32_t h, uint32_t h1, uint32_t h2, uint32_t h3, int w, int min_n, int* cnt, int* first) {
+  const uint32_t ok = intersect_pre_mask(hm1, h, h1, h2, h3, w, min_n);
+  *cnt = __popc(ok);
+  *first = ok ? 32 * w + __ffs(ok) - 1 : 0x7fffffff;
 }
 // the scan on the reversed trace (get_intracePileUp), min_n <= 32: runs of min_n samples that END in word w and do not touch
 // sample n-1; count and the largest end index
