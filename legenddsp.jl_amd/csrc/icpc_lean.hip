@@ -60,7 +60,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int R = 4, SP = 16;
 constexpr int EST_TBL = LDSP_MAX_EST_PTS * (LDSP_MAX_EST_DEG + 1);
-enum { M_T0, M_T0INV, M_INTR, M_FB, NMASKROWS = 8 };   // M_FB..M_FB+4: the general scan of the five y thresholds (rare)
+enum { M_T0, M_T0INV, M_INTR, M_FB, M_SG50 = 8, NMASKROWS = 9 };   // M_FB..M_FB+4: the general scan of the five y thresholds (rare)
 enum { W_TAIL = 0, W_SGB = 3, W_PZ = 5, W_CZ = 8, NWSUM = 10 };   // rows of the per-wave window partial sums
 
 __device__ __forceinline__ f2 mk2(float a, float b) { f2 v; v.x = a; v.y = b; return v; }
@@ -671,31 +671,22 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
     if (thr_intr == 0.f) thr_intr = 1.f;
     thr_sg50 = ford_inv(S.sl->fmx[FX_G]) * 0.5f;
   }
-  // LS pass over the SG output, two rows per step (ds_read2st64): the pile-up mask by ballot (a count of runs is needed),
-  // and t50_current (dsp_icpc.jl:192-195) directly: with tx_mintot = 2 a crossing at k is g[k-1] < thr <= min(g[k], g[k+1]),
-  // with tx_mintot = 1 (presummed traces of dsp_icpc_compressed) g[k-1] < thr <= g[k].
+  // LS pass over the SG output, two rows per step (ds_read2st64): two masks by ballot — the pile-up threshold (a count of runs is
+  // needed) and half the maximum (t50_current, dsp_icpc.jl:192-195: the first run of tx_mintot samples, found by the run scans
+  // below like t0; reading g[k-1] and g[k+1] here for a direct crossing test cost two more LDS reads per sample).
   {
-    int code50 = SP;
-    uint32_t acci = 0u;
-    const bool one = P.tx_mintot == 1;   // (block-uniform; the host sends tx_mintot <= 2 here)
+    uint32_t acci = 0u;   // lanes 0..31: words of the pile-up mask, 32..63: of the half-maximum mask (g = -inf beyond the output: 0)
     const float* gb = &S.B[tid];
 #pragma unroll
     for (int m = SP - 2; m >= 0; m -= 2) {
       const f2 g = mk2(gb[NT * m], gb[NT * (m + 1)]);
-      f2 gm = mk2(gb[NT * m - 1], gb[NT * (m + 1) - 1]);
-      if (m == 0 && tid == 0) gm.x = INFINITY;   // a run that starts the trace is no crossing
-      const f2 gp = mk2(gb[NT * m + 1], gb[NT * (m + 1) + 1]);
-      const float w1 = (gm.y < thr_sg50) ? (one ? g.y : vmin(g.y, gp.y)) : -INFINITY;
-      code50 = (w1 >= thr_sg50) ? m + 1 : code50;
-      const float w0 = (gm.x < thr_sg50) ? (one ? g.x : vmin(g.x, gp.x)) : -INFINITY;
-      code50 = (w0 >= thr_sg50) ? m : code50;
       const unsigned long long ba = __ballot(g.x >= thr_intr), bb = __ballot(g.y >= thr_intr);
+      const unsigned long long bc = __ballot(g.x >= thr_sg50), bd = __ballot(g.y >= thr_sg50);
       put_ballots(acci, ba, bb, 2 * m);
+      put_ballots(acci, bc, bd, 32 + 2 * m);
     }
-    if (lane < 32) S.bm[M_INTR * NWORDS + (NT >> 5) * (lane >> 1) + 2 * wave + (lane & 1)] = acci;
-    uint32_t key = code50 == SP ? 0x7fffffffu : (uint32_t)(tid + NT * code50);
-    LDSP_DPP_GROUP1("v_min_u32_dpp", key);
-    if (lane == 63 && key != 0x7fffffffu) atomicMin(&S.sl->imin[IM_SG50], (int)key);
+    // lane j: mask j >> 5, row (j & 31) >> 1, half j & 1 of the wave's 64-bit word
+    S.bm[((lane >> 5) ? M_SG50 : M_INTR) * NWORDS + (NT >> 5) * ((lane & 31) >> 1) + 2 * wave + (lane & 1)] = acci;
   }
   STAMP(8); DSTOP(8);
 
@@ -886,15 +877,16 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
       p_tx = S.sl->imin[IM_TX0 + q];
     }
   }
-  // Intersect scans on the bit-masks (thread <-> word): t0, inverted t0, in-trace pile-up.  Every word a thread's scans can need is
+  // Intersect scans on the bit-masks (thread <-> word): t0, inverted t0, in-trace pile-up (lower half of the threads), half maximum
+  // of the SG output (upper half).  Every word a thread's scans can need is
   // read first (one wait instead of a dependent LDS round trip per word), and the run tests are loop-free (intersect_pre /
   // intersect_rev_pre); run lengths beyond their windows take the word-by-word forms.
   static_assert(2 * NWORDS == NT, "one t0 / inverted-t0 word per thread");
   if (P.t0_mintot <= 97 && P.intrace_mintot <= 32) {   // block-uniform
     const int q = tid / NWORDS, wd = tid % NWORDS;
     const uint32_t* b0 = S.bm + (M_T0 + q) * NWORDS;
-    const uint32_t* bi = S.bm + M_INTR * NWORDS;
-    const bool has_i = tid < NWORDS;   // (waves of the lower half also take an in-trace word)
+    const bool has_i = tid < NWORDS;   // the lower half also takes an in-trace word, the upper half a word of the half-maximum mask
+    const uint32_t* bi = S.bm + (has_i ? M_INTR : M_SG50) * NWORDS;
     uint32_t t[5], u[3];
 #pragma unroll
     for (int k = 0; k < 5; ++k) t[k] = b0[min(max(wd + k - 1, 0), NWORDS - 1)];
@@ -911,8 +903,16 @@ icpc_lean_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, I
     if (has_i) {
       intersect_rev_pre(u[0], u[1], u[2], wd, ng, P.intrace_mintot, &c, &f);
       if (c) { atomicAdd(&S.sl->isum[IS_INTR], c); atomicMax(&S.sl->imax[0], f); }
+    } else {   // (tx_mintot <= 2 in this kernel)
+      intersect_pre(u[0], u[1], u[2], 0u, 0u, wd, P.tx_mintot, &c, &f);
+      if (c) atomicMin(&S.sl->imin[IM_SG50], f);
     }
   } else {
+    for (int wd = tid; wd < NWORDS; wd += NT) {
+      int c, f;
+      intersect_word(S.bm + M_SG50 * NWORDS, wd, NWORDS, P.tx_mintot, &c, &f);
+      if (c) atomicMin(&S.sl->imin[IM_SG50], f);
+    }
     for (int j = tid; j < 2 * NWORDS; j += NT) {
       const int q = j / NWORDS, wd = j % NWORDS;
       int c, f;
