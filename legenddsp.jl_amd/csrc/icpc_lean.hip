@@ -38,6 +38,7 @@
 #endif
 
 namespace ldsp {
+int g_dbg_lds_pad = 0;   // option "dbg_lds_pad": extra dynamic LDS per workgroup (occupancy experiments, tools/occ_probe.py)
 namespace lean {
 
 typedef __attribute__((address_space(3))) float lds_float;   // explicit LDS pointers: survive being pinned to a VGPR (ds_ instructions, not flat_)
@@ -1589,7 +1590,7 @@ static hipError_t launch_pz_t(const float* wf, int64_t n, bool u16, const IcpcDe
 template <int NT, int M, bool SEP>
 static hipError_t launch_t(const float* wf, int64_t n, const IcpcDev* dP, const IcpcOutDev& out, const float* ext_bl, float ext_bl_scale,
                            int Lf, hipStream_t st) {
-  const size_t smem = Smem<NT>::bytes(cz_pad_floats(Lf));
+  const size_t smem = Smem<NT>::bytes(cz_pad_floats(Lf)) + (size_t)g_dbg_lds_pad;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_lean_kernel<NT, M, SEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((icpc_lean_kernel<NT, M, SEP>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, out, ext_bl, ext_bl_scale);
@@ -1597,7 +1598,6 @@ static hipError_t launch_t(const float* wf, int64_t n, const IcpcDev* dP, const 
 }
 
 }  // namespace lean
-
 // LDS bytes of the lean kernel for a tile of NT threads and CUSP/ZAC filters of Lf taps (the host checks it against the
 // two-traces-per-CU budget before choosing this kernel)
 size_t icpc_lean_smem_bytes(int NT, int Lf) {

@@ -1,0 +1,1499 @@
+// icpc_lean3.hip — the fused dsp_icpc kernel (reference src/dsp_icpc.jl:62-230) for the standard geometry, round 3:
+// THREE workgroups per CU.  Measured on the round-2 kernel (tools/occ_probe.py, tools/stamp_map.py dbg_lds_pad=60000): a workgroup
+// lives 61 000 cycles alone on its CU and 71 800 next to a second one — the chain is a sequence of latencies (DPP chains, LDS
+// round trips, ~20 barriers), the SIMDs and the LDS pipe are half idle, and throughput is nearly proportional to the number of
+// resident workgroups.  A third one needs <= 53 760 B of LDS and <= 80 VGPRs:
+//   * ONE trace-sized LDS array X, used in turns:  T (prefix sum of y: the trapezoid sweeps)  ->  y (Savitzky-Golay halo,
+//     crossings, estimators, pile-up)  ->  Dp, u, PRF, Dp, G, A of the CUSP / ZAC stage.  y lives in registers (S4 view) while X
+//     holds T; the few values of T-based filters that are needed later (the t0 crossing, the 44 points of the e_trap estimate)
+//     are window sums of y taken by one wave — more accurate than differences of a float prefix sum of 1e8.
+//   * sweep A (the t0 trapezoid's two threshold masks) runs in the S4 view: its 2-sample first leg comes from the thread's own
+//     registers (+ two samples of the next lane by DPP), the long leg from two quad reads of T at the trapezoid's shifts
+//     (ds_read_b128 / 2 x b64 / b32 + b64 + b32 by the shift's alignment: tools/micro/lds_s4shift_test.hip);
+//   * the Savitzky-Golay output never goes to LDS: the pile-up and half-maximum masks are built from the registers that hold
+//     it (four predicate bits per thread, eight lanes OR-ed into a word by three DPP steps);
+//   * CUSP / ZAC: the parabola part (u -> double prefix sum -> PRF) is finished BEFORE the flat top and the two one-pole
+//     recursions start, so that at most three 16-sample register arrays are live at any time.
+// Same phases, same summation rules and the same 48 columns as the round-2 kernel; every other parameter set runs icpc_kernel.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <math.h>
+#include <stddef.h>
+#include "icpc_dev.hpp"
+#include "ldsp_device.hpp"
+#include "qdrift.hpp"
+
+#ifdef LDSP_STAMPS
+#define STAMP(id) do { asm volatile("; LDSP_PHASE " #id); if ((threadIdx.x & 63) == 0 && blockIdx.x < LDSP_STAMP_BLOCKS && P.dbg_stamps) \
+    P.dbg_stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * LDSP_STAMP_SLOTS + (id)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(id) asm volatile("; LDSP_PHASE " #id)
+#endif
+#ifdef LDSP_DSTOP
+#define DSTOP(id) do { if (P.dbg_stop == 100 + (id)) return; } while (0)
+#else
+#define DSTOP(id) do { } while (0)
+#endif
+
+namespace ldsp {
+extern int g_dbg_lds_pad;   // option "dbg_lds_pad" (icpc_lean.hip)
+namespace lean3 {
+
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) float __attribute__((ext_vector_type(4))) lds_f4;
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int NW, typename F>
+__device__ __forceinline__ float fold_partials(const lds_float* p, float init, F f) {
+  float acc = init;
+  if constexpr (NW == 8) {
+    const auto a = *(const lds_f4*)p, b = *(const lds_f4*)(p + 4);
+    acc = f(f(f(f(f(f(f(f(acc, a.x), a.y), a.z), a.w), b.x), b.y), b.z), b.w);
+  } else {
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) acc = f(acc, p[ww]);
+  }
+  return acc;
+}
+
+constexpr int R = 4, SP = 16;
+constexpr int EST_TBL = LDSP_MAX_EST_PTS * (LDSP_MAX_EST_DEG + 1);
+enum { M_T0, M_T0INV, M_INTR, M_FB, M_SG50 = 8, NMASKROWS = 9 };   // M_FB..M_FB+4: the general scan of the five y thresholds (rare)
+enum { W_TAIL = 0, W_SGB = 3, W_PZ = 5, W_CZ = 8, NWSUM = 10 };   // rows of the per-wave window partial sums
+
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 v; v.x = a; v.y = b; return v; }
+__device__ __forceinline__ f2 splat(float a) { return mk2(a, a); }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float hsum(f2 v) { return v.x + v.y; }
+__device__ __forceinline__ void pin(f2& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+  const float own = v;
+  LDSP_DPP_GROUP1("v_max_f32_dpp", v);
+  const float vm = readlane_f(v, 63);
+  uint32_t key = (own == vm) ? (uint32_t)i : 0x7fffffffu;
+  LDSP_DPP_GROUP1("v_min_u32_dpp", key);
+  i = (int)key;
+}
+
+struct Pos {  // fractional sample position ip + fp
+  int ip;
+  float fp;
+};
+__device__ __forceinline__ Pos pos_norm(Pos p) {
+  const float f = floorf(p.fp);
+  p.ip += (int)f;
+  p.fp -= f;
+  return p;
+}
+__device__ __forceinline__ Pos pos_add(Pos p, float d) {
+  const float di = floorf(d);
+  p.ip += (int)di;
+  p.fp += d - di;
+  return pos_norm(p);
+}
+__device__ __forceinline__ float est_weight(const EstDev& E, const float* Bt, int l, float u) { return dni_weight(E, Bt, l, u); }
+__device__ __forceinline__ void est_window(const EstDev& E, Pos p, int nsig, int* i0, float* u) {
+  if (p.ip < 0) { p.ip = 0; p.fp = 0.f; }
+  if (p.ip >= nsig - 1) { p.ip = nsig - 1; p.fp = 0.f; }
+  int a = p.ip + (int)ceilf(p.fp - 0.5f * (float)E.npts);
+  a = max(0, min(a, nsig - E.npts));
+  *i0 = a;
+  *u = ((float)(p.ip - a) + p.fp - E.c) * E.s_inv;
+}
+__device__ __forceinline__ float wave_total(float v) {   // sum over the wave, in every lane
+  LDSP_DPP_GROUP1("v_add_f32_dpp", v);
+  return readlane_f(v, 63);
+}
+// sum of Y[from .. from + n) by one wave, in every lane (window sums of y in place of differences of a float prefix sum)
+__device__ __forceinline__ float wave_box(const float* Y, int from, int n, int lane) {
+  float acc = 0.f;
+  for (int j = lane; j < n; j += 64) acc += Y[from + j];
+  return wave_total(acc);
+}
+
+__device__ __forceinline__ void win_finish(float s1, float s2, float sx, const WinDev& w, float pivot, float t_first, float dt,
+                                           float* mean, float* sigma, float* slope, float* offset) {
+  const float inv_n = (float)w.inv_n;
+  const float md = s1 * inv_n, m = pivot + md;
+  const float var = fmaxf(fmaf(s2, inv_n, -md * md), 0.f);
+  const float sl = (sx * inv_n) * __builtin_amdgcn_rcpf((float)w.var_i * dt);
+  *mean = m;
+  *sigma = __builtin_amdgcn_sqrtf(var);
+  *slope = sl;
+  *offset = m - sl * (t_first + (float)w.ic * dt);
+}
+
+struct Slots {   // LDS atomics targets (set to their identities in phase 0)
+  unsigned long long vi[8];   // packed (value, index) maxima: optimised trapezoid, 4 current windows
+  uint32_t fmx[8];            // float maxima as ordered uints: 3 fixed trapezoids, SG maximum, 2 inverted, cusp, zac
+  int isum[4];                // tail_bad, run counts of t0 / inverted t0 / in-trace pile-up
+  int imin[10];               // first index: 5 thresholds, t0, inverted t0, sg50, cusp max, zac max
+  int imax[2];                // last run end (pile-up)
+};
+static_assert(sizeof(Slots) % 8 == 0, "Slots keeps the 8-byte alignment of what follows");
+enum { VI_OPT, VI_CUR0, VI_CUR1, VI_CUR2, VI_CUR3 };
+enum { FX_F0, FX_F1, FX_F2, FX_G, FX_F0I, FX_F2I, FX_CUSP, FX_ZAC };
+enum { IS_TAILBAD, IS_T0, IS_T0INV, IS_INTR };
+enum { IM_TX0 = 0, IM_T0 = 5, IM_T0INV = 6, IM_SG50 = 7, IM_CUSP = 8, IM_ZAC = 9 };
+
+__host__ __device__ inline int cz_pad_floats(int Lf) { return (Lf + 2 + 7) & ~3; }
+
+// LDS: [gap: mask words / Dp[i < 0] = 0][X: Lp + 64][8-byte data][4-byte data][slack]: a lane-strided read X[k + shift] of the row
+// pair that holds the end of an output range runs at most 2 NT floats past X (masked by the caller): those addresses stay
+// inside the allocation.
+template <int NT>
+struct Smem {
+  static constexpr int NW = NT / 64, Lp = NT * SP, NWORDS = Lp / 32;
+  static constexpr int NSMALL = 2 * R * NW /*part*/ + 3 * R * NW /*scn*/ + 5 * NW /*wred*/ + NWSUM * NW /*wsum*/ + C_NCOLS + 32 /*outv, misc*/ +
+                                2 * EST_TBL + 2 * (R * NW + 1) /*hy*/;
+  uint32_t* bm;    // [NMASKROWS][NWORDS] in the gap in front of X
+  float* X;        // [Lp + 64]
+  double* dpart;   // [2][R*NW]  double prefix sum of the ZAC parabolas
+  Slots* sl;
+  float* part;     // [2][R*NW]  wave-row totals of the block scans (alternating buffers)
+  float* scn;      // [3][R*NW]  what wave 0 makes of them (pz offsets; T offsets hi, lo)
+  float* estB;     // [2][EST_TBL]
+  float* hy;       // [R*NW + 1][2]  first two samples of y of every wave-row (time order), then zeros: the halo of a wave's lane 63
+  lds_float* wred;     // [5][NW]    phase-1 per-wave partials: s1, s2, sx, max, min
+  lds_float* wsum;     // [NWSUM][NW]
+  lds_float* outv;     // [C_NCOLS]
+  lds_float* misc;     // [32]
+  static constexpr int gap_floats(int cz_pad) { return NMASKROWS * NWORDS > cz_pad ? NMASKROWS * NWORDS : cz_pad; }
+  static constexpr size_t tail_bytes() {
+    const size_t used = (size_t)2 * R * NW * 8 + sizeof(Slots) + (size_t)NSMALL * 4;
+    const size_t slack = (size_t)2 * NT * 4 + 256;
+    return used > slack ? used : slack;
+  }
+  static constexpr size_t bytes(int cz_pad) { return (size_t)(Lp + 64 + gap_floats(cz_pad)) * 4 + tail_bytes() + 64; }
+  __device__ Smem(unsigned char* raw, int cz_pad) {
+    bm = reinterpret_cast<uint32_t*>(raw);
+    X = reinterpret_cast<float*>(raw) + gap_floats(cz_pad);
+    dpart = reinterpret_cast<double*>(X + Lp + 64);
+    sl = reinterpret_cast<Slots*>(dpart + 2 * R * NW);
+    part = reinterpret_cast<float*>(sl + 1);
+    scn = part + 2 * R * NW;
+    estB = scn + 3 * R * NW;
+    hy = estB + 2 * EST_TBL;
+    float* wred_ = hy + 2 * (R * NW + 1);
+    lds_float* base = (lds_float*)wred_;
+    asm volatile("" : "+v"(base));   // one VGPR base for the small arrays (they lie beyond the reach of a zero-based immediate)
+    wred = base;
+    wsum = base + 5 * NW;
+    outv = wsum + NWSUM * NW;
+    misc = outv + C_NCOLS;
+  }
+};
+
+// Accumulators of a window's sums in the S4 view, as register pairs (see icpc_lean.hip, round 2)
+struct WAcc {
+  f2 s1, s2, se, sr;
+};
+__device__ __forceinline__ void wacc_quad(WAcc& a, f2 d0, f2 d1, int r) {
+  const f2 t = d0 + d1;
+  a.s1 += t;
+  if (r) a.sr = fma2(t, splat((float)r), a.sr);
+  a.s2 = fma2(d0, d0, a.s2);
+  a.s2 = fma2(d1, d1, a.s2);
+  a.se = fma2(d0, mk2(0.f, 1.f), a.se);
+  a.se = fma2(d1, mk2(2.f, 3.f), a.se);
+}
+template <int NT>
+__device__ __forceinline__ void wacc_lane(const WAcc& a, int tid, float ic, float* s1, float* s2, float* sx) {
+  *s1 = hsum(a.s1);
+  *s2 = hsum(a.s2);
+  *sx = fmaf((float)(4 * tid) - ic, *s1, fmaf((float)(4 * NT), hsum(a.sr), hsum(a.se)));
+}
+
+// cross-wave prefix sums of the wave-row totals by ONE wave (see icpc_lean.hip)
+template <int NW>
+__device__ __forceinline__ double row_prefix_f64(const float* part, int lane, double* total) {
+  const int jr = lane / NW, jw = lane - jr * NW;   // lane j <-> wave-row (r = jr, w = jw)
+  const double pvv = (lane < R * NW) ? (double)part[4 * jw + jr] : 0.0;
+  const double pinc = wave_incl_scan_sum_f64(pvv);
+  if (total) *total = readlane_d(pinc, R * NW - 1);
+  return pinc - pvv;
+}
+template <int NW>
+__device__ __forceinline__ void pz_offsets_scan(const float* part, float* scn, double pz_c64, int wave, int lane) {
+  if (wave != 0) return;
+  const double ex = row_prefix_f64<NW>(part, lane, nullptr);
+  const int jr = lane / NW, jw = lane - jr * NW;
+  if (lane < R * NW) scn[4 * jw + jr] = (float)(pz_c64 * ex);
+}
+template <int NW>
+__device__ __forceinline__ void pz_apply(f4 (&x)[R], const float (&inc)[R], const float (&tot)[R], const float* scn, float pz_c, int wave) {
+  const f4 co = *reinterpret_cast<const f4*>(&scn[4 * wave]);
+  const float cw[R] = {co.x, co.y, co.z, co.w};
+  const f2 c2 = splat(pz_c);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float coff = fmaf(pz_c, inc[r] - tot[r], cw[r]);   // c * (sum of x before this lane's quad)
+    const float r1 = x[r].x + x[r].y, r2 = r1 + x[r].z, r3 = r2 + x[r].w;   // running sums inside the quad
+    const f2 cf = splat(coff);
+    x[r].xy = fma2(c2, mk2(x[r].x, r1), x[r].xy + cf);
+    x[r].zw = fma2(c2, mk2(r2, r3), x[r].zw + cf);
+  }
+}
+template <int NW>
+__device__ __forceinline__ void t_offsets_scan(const float* part, float* hilo, float* t_end, int wave, int lane) {
+  if (wave != 0) return;
+  double total;
+  const double ex = row_prefix_f64<NW>(part, lane, &total);
+  const int jr = lane / NW, jw = lane - jr * NW;
+  const float hi = (float)ex;
+  if (lane < R * NW) { hilo[4 * jw + jr] = hi; hilo[R * NW + 4 * jw + jr] = (float)(ex - (double)hi); }
+  if (lane == 0) *t_end = (float)total;
+}
+// T of a quad = hi + (lo + (sum inside the wave-row before the sample)): one rounding at the magnitude of T
+__device__ __forceinline__ f4 t_quad(f4 y, float p0, float hw, float lw) {
+  const float p1 = p0 + y.x, p2 = p1 + y.y, p3 = p2 + y.z;
+  const f2 h2 = splat(hw), lo2 = splat(lw);
+  const f2 ta = h2 + (lo2 + mk2(p0, p1)), tb = h2 + (lo2 + mk2(p2, p3));
+  return (f4){ta.x, ta.y, tb.x, tb.y};
+}
+
+// a thread's quad of a LINEAR LDS array at an arbitrary index (al = idx & 3, block-uniform): the widest reads the alignment
+// allows (a 4-byte-aligned ds_read_b64 is 19x slower than an aligned one, two ds_read2_b32 of adjacent words 5x:
+// tools/micro/lds_b64_test.hip, lds_s4shift_test.hip)
+__device__ __forceinline__ f4 rdq(const float* X, int idx, int al) {
+  if (al == 0) return *reinterpret_cast<const f4*>(&X[idx]);
+  if (al == 2) {
+    const f2 a = *reinterpret_cast<const f2*>(&X[idx]), b = *reinterpret_cast<const f2*>(&X[idx + 2]);
+    return (f4){a.x, a.y, b.x, b.y};
+  }
+  const float a = X[idx];
+  const f2 m = *reinterpret_cast<const f2*>(&X[idx + 1]);
+  const float d = X[idx + 3];
+  return (f4){a, m.x, m.y, d};
+}
+// the four predicate bits of a thread's quad -> bits [4 (lane & 7), +4) of the word of its group of eight lanes; complete in
+// the lanes with (lane & 7) == 7 (row_shr inside a row of 16 lanes, zeros shifted in)
+__device__ __forceinline__ uint32_t s4_pack_word(uint32_t nib, int lane) {
+  uint32_t v = nib << (4 * (lane & 7));
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+  return v;
+}
+__device__ __forceinline__ uint32_t nib_ge(f4 v, float t) {
+  return (uint32_t)(v.x >= t) | ((uint32_t)(v.y >= t) << 1) | ((uint32_t)(v.z >= t) << 2) | ((uint32_t)(v.w >= t) << 3);
+}
+__device__ __forceinline__ uint32_t nib_le(f4 v, float t) {
+  return (uint32_t)(v.x <= t) | ((uint32_t)(v.y <= t) << 1) | ((uint32_t)(v.z <= t) << 2) | ((uint32_t)(v.w <= t) << 3);
+}
+
+// LDSP_L3_WPS: minimum waves per SIMD the register allocation is bounded for (6: three 512-thread workgroups per CU, <= 80 VGPRs)
+#ifndef LDSP_L3_WPS
+#define LDSP_L3_WPS 6
+#endif
+// SEP: CUSP and ZAC have their own geometry (two passes of the closed-form stage); keeps a second copy of y in registers
+template <int NT, int M, bool SEP>
+__global__ void __launch_bounds__(NT, SEP ? 4 : LDSP_L3_WPS)
+icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOutDev out, const float* __restrict__ ext_bl,
+                  float ext_bl_scale) {
+  using SM = Smem<NT>;
+  constexpr int NW = SM::NW, Lp = SM::Lp, NWORDS = SM::NWORDS, L = Lp;
+  static_assert(R * NW <= 64, "wave-row partials must fit one wave");
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const IcpcDev& P = *Pp;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Lf_max = max(P.cusp.Lf, P.zac.Lf);
+  SM S(smem_raw, cz_pad_floats(Lf_max));
+  const float* w = wf + (size_t)blockIdx.x * (size_t)L;
+  auto wrow = [&](int r) { return 4 * (64 * wave + NT * r); };
+  enum { WN_BL, WN_TAIL, WN_SGBL, WN_CUR0, WN_CURX };
+  const uint32_t cls_bl = P.rowcls[WN_BL][wave], cls_tail = P.rowcls[WN_TAIL][wave], cls_sgbl = P.rowcls[WN_SGBL][wave],
+                 cls_cur0 = P.rowcls[WN_CUR0][wave], cls_curx = P.rowcls[WN_CURX][wave];
+  auto row_out = [&](uint32_t cls, int r) { return ((cls >> r) & 1u) != 0u; };
+  auto row_in = [&](uint32_t cls, int r) { return ((cls >> (4 + r)) & 1u) != 0u; };
+
+  // ------------------------------------------------------------------------------------------------ phase 0: load
+  STAMP(0); DSTOP(0);
+  f4 x[R];
+  const uint16_t* w16 = reinterpret_cast<const uint16_t*>(wf) + (size_t)blockIdx.x * (size_t)L;
+  auto wv = [&](int i) { return P.in_u16 ? (float)w16[i] : w[i]; };
+  if (P.in_u16) {   // (block-uniform)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint2 q = *reinterpret_cast<const uint2*>(w16 + 4 * (tid + NT * r));
+      x[r] = (f4){(float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16)};
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
+  }
+  const float pv_bl = wv(P.bl.from);      // pivot of the baseline sums: the window's first sample
+  for (int i = tid; i < 2 * EST_TBL; i += NT)   // LSQ basis tables of the two estimators -> LDS
+    S.estB[i] = (i < EST_TBL) ? P.sig_est.B[i] : P.int_est.B[i - EST_TBL];
+  if (tid < (int)(sizeof(Slots) / 4)) {
+    const int o = tid * 4;
+    uint32_t init = 0;
+    if (o >= (int)offsetof(Slots, imin) && o < (int)offsetof(Slots, imax)) init = 0x7fffffffu;
+    else if (o >= (int)offsetof(Slots, imax)) init = 0xffffffffu;   // -1
+    reinterpret_cast<uint32_t*>(S.sl)[tid] = init;
+  }
+  if (tid < 64) S.X[Lp + tid] = 0.f;
+  if (tid < 2) S.hy[2 * R * NW + tid] = 0.f;
+
+  // ---------------------------------------------------------------------------------- phase 1: raw extremes, baseline sums
+  {
+    float rmax = vmax3(x[0].x, x[0].y, x[0].z), rmin = vmin3(x[0].x, x[0].y, x[0].z);
+    rmax = vmax3(rmax, x[0].w, x[1].x); rmin = vmin3(rmin, x[0].w, x[1].x);
+    rmax = vmax3(rmax, x[1].y, x[1].z); rmin = vmin3(rmin, x[1].y, x[1].z);
+    rmax = vmax3(rmax, x[1].w, x[2].x); rmin = vmin3(rmin, x[1].w, x[2].x);
+    rmax = vmax3(rmax, x[2].y, x[2].z); rmin = vmin3(rmin, x[2].y, x[2].z);
+    rmax = vmax3(rmax, x[2].w, x[3].x); rmin = vmin3(rmin, x[2].w, x[3].x);
+    rmax = vmax3(rmax, x[3].y, x[3].z); rmin = vmin3(rmin, x[3].y, x[3].z);
+    rmax = vmax(rmax, x[3].w); rmin = vmin(rmin, x[3].w);
+    WAcc a = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
+    const f2 pv = splat(pv_bl);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (row_out(cls_bl, r)) continue;
+      f2 d0 = x[r].xy - pv, d1 = x[r].zw - pv;
+      if (!row_in(cls_bl, r)) {
+        const int lo = P.bl.from - 4 * (tid + NT * r), hi = P.bl.until - 4 * (tid + NT * r);   // in-window e in [lo, hi]
+        d0.x = (lo <= 0 && hi >= 0) ? d0.x : 0.f; d0.y = (lo <= 1 && hi >= 1) ? d0.y : 0.f;
+        d1.x = (lo <= 2 && hi >= 2) ? d1.x : 0.f; d1.y = (lo <= 3 && hi >= 3) ? d1.y : 0.f;
+      }
+      wacc_quad(a, d0, d1, r);
+    }
+    float s1, s2, sx;
+    wacc_lane<NT>(a, tid, (float)P.bl.ic, &s1, &s2, &sx);
+    LDSP_DPP_GROUP5("v_add_f32_dpp", s1, "v_add_f32_dpp", s2, "v_add_f32_dpp", sx, "v_max_f32_dpp", rmax, "v_min_f32_dpp", rmin);
+    if (lane == 63) {
+      S.wred[0 * NW + wave] = s1; S.wred[1 * NW + wave] = s2; S.wred[2 * NW + wave] = sx;
+      S.wred[3 * NW + wave] = rmax; S.wred[4 * NW + wave] = rmin;
+    }
+  }
+  STAMP(1); DSTOP(1);
+  __syncthreads();
+  float blmean, raw_max, raw_min;
+  {
+    const float s = fold_partials<NW>(S.wred, 0.f, [](float a, float b) { return a + b; });
+    const float mx = fold_partials<NW>(S.wred + 3 * NW, -INFINITY, [](float a, float b) { return vmax(a, b); });
+    const float mn = fold_partials<NW>(S.wred + 4 * NW, INFINITY, [](float a, float b) { return vmin(a, b); });
+    blmean = fmaf(s, (float)P.bl.inv_n, pv_bl);
+    if (ext_bl) blmean = ext_bl[blockIdx.x] * ext_bl_scale;   // windowed traces of dsp_icpc_compressed (dsp_icpc.jl:353)
+    raw_max = mx; raw_min = mn;
+    if (tid == 64 % NT) {   // a lane of wave 1 (wave 0 for one-wave tiles): sigma, slope, offset
+      float s2 = 0.f, sx = 0.f;
+      for (int ww = 0; ww < NW; ++ww) { s2 += S.wred[NW + ww]; sx += S.wred[2 * NW + ww]; }
+      float m_, blsigma, blslope, bloffset;
+      win_finish(s, s2, sx, P.bl, pv_bl, P.t_first, P.dt, &m_, &blsigma, &blslope, &bloffset);
+      S.outv[C_blmean] = blmean; S.outv[C_blsigma] = blsigma; S.outv[C_blslope] = blslope; S.outv[C_bloffset] = bloffset;
+      S.outv[C_e_max] = raw_max - blmean; S.outv[C_e_min] = raw_min - blmean;
+    }
+  }
+  const float e_max = raw_max - blmean;
+  STAMP(2); DSTOP(2);
+
+  // saturation (src/saturation.jl:28-65): only a trace whose extremes reach a rail can have saturated samples
+  {
+    int n_low = 0, n_high = 0, cons_low = 0, cons_high = 0;
+    if (raw_min <= P.sat_low || raw_max >= P.sat_high) {   // block-uniform, rare
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        n_low += (x[r].x == P.sat_low) + (x[r].y == P.sat_low) + (x[r].z == P.sat_low) + (x[r].w == P.sat_low);
+        n_high += (x[r].x == P.sat_high) + (x[r].y == P.sat_high) + (x[r].z == P.sat_high) + (x[r].w == P.sat_high);
+        *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = x[r];
+      }
+      n_low = wave_sum_all_i(n_low); n_high = wave_sum_all_i(n_high);
+      if (lane == 0) { atomicAdd(&S.sl->imax[0], n_low); atomicAdd(&S.sl->imax[1], n_high); }   // the slots start at -1
+      __syncthreads();
+      for (int m = 0; m < SP; ++m) {
+        const float v = S.X[tid + NT * m];
+        ballot_store(v == P.sat_low, S.bm + M_FB * NWORDS, (NT >> 5) * m + 2 * wave);
+        ballot_store(v == P.sat_high, S.bm + (M_FB + 1) * NWORDS, (NT >> 5) * m + 2 * wave);
+      }
+      __syncthreads();
+      n_low = S.sl->imax[0] + 1; n_high = S.sl->imax[1] + 1;   // the slots started at -1
+      if (tid < 2) {
+        const uint32_t* b = S.bm + (M_FB + tid) * NWORDS;
+        int best = 0, run = 0;
+        for (int wd = 0; wd < NWORDS; ++wd) {
+          const uint32_t v = b[wd];
+          if (v == 0xffffffffu) { run += 32; continue; }
+          if (v == 0) { best = max(best, run); run = 0; continue; }
+          for (int bb = 0; bb < 32; ++bb) {
+            if ((v >> bb) & 1u) ++run;
+            else { best = max(best, run); run = 0; }
+          }
+        }
+        S.misc[tid] = __int_as_float(max(best, run));
+      }
+      __syncthreads();
+      cons_low = __float_as_int(S.misc[0]); cons_high = __float_as_int(S.misc[1]);
+      __syncthreads();
+      if (tid < 2) S.sl->imax[tid] = -1;
+    }
+    if (tid == 0) {
+      S.outv[C_n_sat_low] = __int_as_float(n_low); S.outv[C_n_sat_high] = __int_as_float(n_high);
+      S.outv[C_n_sat_low_cons] = __int_as_float(cons_low); S.outv[C_n_sat_high_cons] = __int_as_float(cons_high);
+    }
+  }
+
+  // ------------------------------------------------------- phase 2: shift, tailstats sums, cumulative sum for the pole-zero
+  const float pv_tl = __logf(fmaxf(wv(P.tail.from) - blmean, 1e-30f));   // pivot of the log sums
+  float inc[R], tot[R];
+  {
+    const f2 bm2 = splat(blmean);
+    WAcc a = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
+    float tmin = INFINITY;   // smallest in-window sample: tailstats returns zeros if any is <= 0 (:27-33)
+    const f2 pv = splat(pv_tl);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      x[r].xy -= bm2; x[r].zw -= bm2;
+      const f2 t = x[r].xy + x[r].zw;
+      tot[r] = t.x + t.y;
+      if (row_out(cls_tail, r)) continue;
+      f2 v0 = x[r].xy, v1 = x[r].zw;
+      const bool edge = !row_in(cls_tail, r);
+      const int lo = P.tail.from - 4 * (tid + NT * r), hi = P.tail.until - 4 * (tid + NT * r);
+      if (edge) {   // samples outside the window must not trip the sign test
+        v0.x = (lo <= 0 && hi >= 0) ? v0.x : 1.f; v0.y = (lo <= 1 && hi >= 1) ? v0.y : 1.f;
+        v1.x = (lo <= 2 && hi >= 2) ? v1.x : 1.f; v1.y = (lo <= 3 && hi >= 3) ? v1.y : 1.f;
+      }
+      tmin = vmin3(tmin, v0.x, v0.y); tmin = vmin3(tmin, v1.x, v1.y);
+      f2 d0 = mk2(__logf(fmaxf(v0.x, 1e-30f)), __logf(fmaxf(v0.y, 1e-30f))) - pv;
+      f2 d1 = mk2(__logf(fmaxf(v1.x, 1e-30f)), __logf(fmaxf(v1.y, 1e-30f))) - pv;
+      if (edge) {
+        d0.x = (lo <= 0 && hi >= 0) ? d0.x : 0.f; d0.y = (lo <= 1 && hi >= 1) ? d0.y : 0.f;
+        d1.x = (lo <= 2 && hi >= 2) ? d1.x : 0.f; d1.y = (lo <= 3 && hi >= 3) ? d1.y : 0.f;
+      }
+      wacc_quad(a, d0, d1, r);
+    }
+    float s1, s2, sx;
+    wacc_lane<NT>(a, tid, (float)P.tail.ic, &s1, &s2, &sx);
+#pragma unroll
+    for (int r = 0; r < R; ++r) inc[r] = tot[r];
+    LDSP_DPP_GROUP8("v_add_f32_dpp", inc[0], "v_add_f32_dpp", inc[1], "v_add_f32_dpp", inc[2], "v_add_f32_dpp", inc[3], "v_add_f32_dpp", s1, "v_add_f32_dpp", s2, "v_add_f32_dpp", sx, "v_min_f32_dpp", tmin);
+    if (lane == 63) {
+      *reinterpret_cast<f4*>(&S.part[4 * wave]) = (f4){inc[0], inc[1], inc[2], inc[3]};   // [wave][r]
+      S.wsum[(W_TAIL + 0) * NW + wave] = s1; S.wsum[(W_TAIL + 1) * NW + wave] = s2; S.wsum[(W_TAIL + 2) * NW + wave] = sx;
+      if (tmin <= 0.f) S.sl->isum[IS_TAILBAD] = 1;   // any wave may set it (same value)
+    }
+  }
+  STAMP(3); DSTOP(3);
+  __syncthreads();
+  pz_offsets_scan<NW>(S.part, S.scn, P.pz_c64, wave, lane);
+  if (tid == (128 % NT)) {   // a lane of wave 2: tailstats -> (mean, sigma, tau)
+    float tail_mean = 0.f, tail_sigma = 0.f, tail_tau = 0.f;
+    if (S.sl->isum[IS_TAILBAD] == 0) {
+      float s1 = 0.f, s2 = 0.f, sx = 0.f, sl, of;
+      for (int ww = 0; ww < NW; ++ww) { s1 += S.wsum[(W_TAIL + 0) * NW + ww]; s2 += S.wsum[(W_TAIL + 1) * NW + ww]; sx += S.wsum[(W_TAIL + 2) * NW + ww]; }
+      win_finish(s1, s2, sx, P.tail, pv_tl, P.t_first, P.dt, &tail_mean, &tail_sigma, &sl, &of);
+      tail_tau = -__builtin_amdgcn_rcpf(sl);
+    }
+    S.outv[C_tail_tau] = tail_tau; S.outv[C_tail_mean] = tail_mean; S.outv[C_tail_sigma] = tail_sigma;
+  }
+  // InvCRFilter: y = x + c*cumsum(x)  (dsp_icpc.jl:119-120); x becomes y
+  __syncthreads();
+  pz_apply<NW>(x, inc, tot, S.scn, P.pz_c, wave);
+  auto& y = x;
+  STAMP(4); DSTOP(4);
+
+  // get_threshold at 10 / 50 / 80 / 90 / 99 % of the pre-PZ maximum (dsp_icpc.jl:132-136): first quad of this wave reaching
+  // each threshold (ballots on the quad maxima); confirmed later, when y is in LDS.
+  const float thr_tx[5] = {e_max * 0.1f, e_max * 0.5f, e_max * 0.8f, e_max * 0.9f, e_max * 0.99f};
+  if (e_max > 0.f) {
+    int qfirst[5] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    bool all_found = false;   // wave-uniform
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (all_found) continue;
+      const float qm = vmax(vmax3(y[r].x, y[r].y, y[r].z), y[r].w);
+      const unsigned long long b0 = __ballot(qm >= thr_tx[0]);
+      if (b0 == 0ull) continue;
+      const unsigned long long b4 = __ballot(qm >= thr_tx[4]);
+      unsigned long long bq[5] = {b0, b0, b0, b0, b4};
+      if (b0 != b4) { bq[1] = __ballot(qm >= thr_tx[1]); bq[2] = __ballot(qm >= thr_tx[2]); bq[3] = __ballot(qm >= thr_tx[3]); }
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+        if (bq[q] && qfirst[q] == 0x7fffffff) qfirst[q] = NT * r + 64 * wave + (int)__builtin_ctzll(bq[q]);
+      all_found = qfirst[4] != 0x7fffffff;
+    }
+    if (lane < 5) {
+      const int qq = lane == 0 ? qfirst[0] : lane == 1 ? qfirst[1] : lane == 2 ? qfirst[2] : lane == 3 ? qfirst[3] : qfirst[4];
+      if (qq != 0x7fffffff) atomicMin(&S.sl->imin[IM_TX0 + lane], qq);
+    }
+  }
+
+  // ------------------------------------------------------------------------------------ phase 3: T = prefix sum of y -> X
+  {   // pivot of signalstats(pole-zero corrected tail): the window's first sample, from its owner's registers
+    const int tq = P.tail.from >> 2, tr = tq / NT, te = P.tail.from & 3;   // (block-uniform)
+    if (tid == tq - NT * tr) {
+      const f4 v = (tr == 0) ? y[0] : (tr == 1) ? y[1] : (tr == 2) ? y[2] : y[3];
+      S.misc[14] = (te == 0) ? v.x : (te == 1) ? v.y : (te == 2) ? v.z : v.w;
+    }
+  }
+  {
+    float tin[R], p0[R];   // p0: sum of the wave-row's samples before this lane's quad
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const f2 t = y[r].xy + y[r].zw; tot[r] = t.x + t.y; tin[r] = tot[r]; }
+    LDSP_DPP_GROUP4("v_add_f32_dpp", tin[0], "v_add_f32_dpp", tin[1], "v_add_f32_dpp", tin[2], "v_add_f32_dpp", tin[3]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) p0[r] = tin[r] - tot[r];
+    float* pb = S.part + R * NW;   // second buffer
+    if (lane == 63) *reinterpret_cast<f4*>(&pb[4 * wave]) = (f4){tin[0], tin[1], tin[2], tin[3]};
+    if (lane == 0) {   // the first two samples of every wave-row: halo of the previous wave-row's last lane (sweep A)
+#pragma unroll
+      for (int r = 0; r < R; ++r) *reinterpret_cast<f2*>(&S.hy[2 * (r * NW + wave)]) = y[r].xy;
+    }
+    __syncthreads();
+    t_offsets_scan<NW>(pb, S.scn + R * NW, &S.X[Lp], wave, lane);   // wave 0; T[L] -> X[Lp]
+    __syncthreads();
+    const float* hilo = S.scn + R * NW;
+    const f4 h = *reinterpret_cast<const f4*>(&hilo[4 * wave]), l = *reinterpret_cast<const f4*>(&hilo[R * NW + 4 * wave]);
+    const float hw[R] = {h.x, h.y, h.z, h.w}, lw[R] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int r = 0; r < R; ++r) *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = t_quad(y[r], p0[r], hw[r], lw[r]);
+  }
+  __syncthreads();
+  STAMP(5); DSTOP(5);
+
+  // ------------------------------------------------------------------------------------ phase 4: sweeps over T
+  {
+    // ---- sweep A, S4 view: the two threshold masks of the t0 trapezoid (get_t0, dsp_routines.jl:9-25; inverted: dsp_icpc.jl:207).
+    // o'[k] = (T[k+flen] - T[k+n1+g]) * (inv2/inv1) - (first leg's sum).  A first leg of <= 3 samples (get_t0's 40 ns) is summed
+    // from y itself — the thread's quad and the first two samples of the next lane's: on the tail T is 1e7..1e8 and a difference
+    // of two of its float values is good to 1..8 counts, the size of the threshold the INVERTED trace is tested against there.
+    {
+      const TrapDev t0 = P.t0;
+      const int nout = L - t0.flen + 1;
+      const float thr0 = P.t0_thr * t0.navg, mthr0 = -thr0;
+      const int s_b = t0.n1 + t0.g, s_c = t0.flen;
+      const bool short1 = t0.n1 <= 3;
+      uint32_t wp[R], wn[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        wp[r] = 0u; wn[r] = 0u;
+        if (4 * NT * r >= nout) continue;   // row beyond the output range
+        const int i0 = 4 * (tid + NT * r);
+        const int ic = min(i0, (nout - 1) & ~3);   // quads beyond the output range read the last one's addresses (masked below)
+        const f4 tb4 = rdq(S.X, ic + s_b, s_b & 3), tc4 = rdq(S.X, ic + s_c, s_c & 3);
+        f4 sl;
+        if (short1) {
+          float h0 = wave_shl1(y[r].x), h1 = wave_shl1(y[r].y);   // the next lane's first two samples
+          const f2 hn = *reinterpret_cast<const f2*>(&S.hy[2 * (r * NW + wave + 1)]);   // ... of the next wave-row, for lane 63
+          h0 = (lane == 63) ? hn.x : h0; h1 = (lane == 63) ? hn.y : h1;
+          sl = y[r];
+          if (t0.n1 >= 2) sl += (f4){y[r].y, y[r].z, y[r].w, h0};
+          if (t0.n1 >= 3) sl += (f4){y[r].z, y[r].w, h0, h1};
+        } else {
+          sl = rdq(S.X, ic + t0.n1, t0.n1 & 3) - *reinterpret_cast<const f4*>(&S.X[ic]);
+        }
+        f4 o;
+        o.xy = fma2(tc4.xy - tb4.xy, splat(t0.rr), -sl.xy);
+        o.zw = fma2(tc4.zw - tb4.zw, splat(t0.rr), -sl.zw);
+        if (4 * NT * (r + 1) > nout) {   // the row that holds the end of the output range: NaN fails both comparisons
+          o.x = (i0 + 0 < nout) ? o.x : NAN; o.y = (i0 + 1 < nout) ? o.y : NAN;
+          o.z = (i0 + 2 < nout) ? o.z : NAN; o.w = (i0 + 3 < nout) ? o.w : NAN;
+        }
+        wp[r] = s4_pack_word(nib_ge(o, thr0), lane);
+        wn[r] = s4_pack_word(nib_le(o, mthr0), lane);   // -trap >= thr
+      }
+      static_assert(M_T0INV == M_T0 + 1, "mask order");
+      if ((lane & 7) == 7) {   // word of (row r, wave, lane group): samples 4 (64 wave + 8 (lane >> 3) + NT r) ..
+        uint32_t* bw = S.bm + M_T0 * NWORDS + 8 * wave + (lane >> 3);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { bw[(NT / 8) * r] = wp[r]; bw[NWORDS + (NT / 8) * r] = wn[r]; }
+      }
+    }
+    STAMP(6); DSTOP(6);
+    // ---- sweep B, LS view: extrema of the three fixed trapezoids, arg-max of the optimised one (dsp_icpc.jl:147-164, 202-204);
+    // two rows per step (one ds_read2st64_b32 per shift), packed arithmetic
+    const float* tb = &S.X[tid];
+    auto rd2 = [&](const float* p, int m) { return mk2(p[NT * m], p[NT * (m + 1)]); };
+    float mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY, mn0 = INFINITY, mn2 = INFINITY;
+    float bo_v = -INFINITY; int bo_i = 0x7fffffff;
+    {
+      const TrapDev f0 = P.fixed[0], f1 = P.fixed[1], f2_ = P.fixed[2], fo = P.opt;
+      const float *f0a = tb + f0.n1, *f0b = tb + f0.n1 + f0.g, *f0c = tb + f0.flen;
+      const float *f1a = tb + f1.n1, *f1b = tb + f1.n1 + f1.g, *f1c = tb + f1.flen;
+      const float *f2a = tb + f2_.n1, *f2b = tb + f2_.n1 + f2_.g, *f2c = tb + f2_.flen;
+      const float *foa = tb + fo.n1, *fob = tb + fo.n1 + fo.g, *foc = tb + fo.flen;
+      const f2 rr0 = splat(f0.rr), rr1 = splat(f1.rr), rr2 = splat(f2_.rr), rro = splat(fo.rr);
+      const int n0 = L - f0.flen + 1, n1 = L - f1.flen + 1, n2 = L - f2_.flen + 1, no = L - fo.flen + 1;
+      const int nall = min(min(n0, n1), min(n2, no));
+#pragma unroll
+      for (int m = 0; m < SP; m += 2) {
+        if (NT * m >= max(max(n0, n1), max(n2, no))) continue;   // pair beyond every output range
+        const f2 Tk = rd2(tb, m);
+        const f2 a0 = rd2(f0a, m), b0 = rd2(f0b, m), c0_ = rd2(f0c, m);
+        const f2 a1 = rd2(f1a, m), b1 = rd2(f1b, m), c1_ = rd2(f1c, m);
+        const f2 a2 = rd2(f2a, m), b2 = rd2(f2b, m), c2_ = rd2(f2c, m);
+        const f2 ao = rd2(foa, m), bo = rd2(fob, m), co = rd2(foc, m);
+        f2 o0 = fma2(c0_ - b0, rr0, Tk - a0), o1 = fma2(c1_ - b1, rr1, Tk - a1), o2 = fma2(c2_ - b2, rr2, Tk - a2), oo = fma2(co - bo, rro, Tk - ao);
+        if (NT * (m + 2) <= nall) {   // pair wholly inside every output range (most pairs)
+          mx0 = vmax3(mx0, o0.x, o0.y); mn0 = vmin3(mn0, o0.x, o0.y);
+          mx1 = vmax3(mx1, o1.x, o1.y);
+          mx2 = vmax3(mx2, o2.x, o2.y); mn2 = vmin3(mn2, o2.x, o2.y);
+        } else {
+          const int k0 = tid + NT * m, k1 = k0 + NT;
+          mx0 = vmax3(mx0, k0 < n0 ? o0.x : -INFINITY, k1 < n0 ? o0.y : -INFINITY);
+          mn0 = vmin3(mn0, k0 < n0 ? o0.x : INFINITY, k1 < n0 ? o0.y : INFINITY);
+          mx1 = vmax3(mx1, k0 < n1 ? o1.x : -INFINITY, k1 < n1 ? o1.y : -INFINITY);
+          mx2 = vmax3(mx2, k0 < n2 ? o2.x : -INFINITY, k1 < n2 ? o2.y : -INFINITY);
+          mn2 = vmin3(mn2, k0 < n2 ? o2.x : INFINITY, k1 < n2 ? o2.y : INFINITY);
+          oo.x = k0 < no ? oo.x : -INFINITY; oo.y = k1 < no ? oo.y : -INFINITY;
+        }
+        if (oo.x > bo_v) { bo_v = oo.x; bo_i = tid + NT * m; }
+        if (oo.y > bo_v) { bo_v = oo.y; bo_i = tid + NT * (m + 1); }
+      }
+      mx0 *= f0.inv1; mn0 *= f0.inv1; mx1 *= f1.inv1; mx2 *= f2_.inv1; mn2 *= f2_.inv1; bo_v *= fo.inv1;
+    }
+    STAMP(7); DSTOP(7);
+    // signalstats of the pole-zero corrected tail (dsp_icpc.jl:122) from the registers, pivot = its first sample
+    float t1, t2, tx;
+    {
+      WAcc a = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
+      const f2 pvz = splat(S.misc[14]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (row_out(cls_tail, r)) continue;
+        const int i0 = 4 * (tid + NT * r);
+        f2 d0 = y[r].xy - pvz, d1 = y[r].zw - pvz;
+        if (!row_in(cls_tail, r)) {
+          const int lo = P.tail.from - i0, hi = P.tail.until - i0;
+          d0.x = (lo <= 0 && hi >= 0) ? d0.x : 0.f; d0.y = (lo <= 1 && hi >= 1) ? d0.y : 0.f;
+          d1.x = (lo <= 2 && hi >= 2) ? d1.x : 0.f; d1.y = (lo <= 3 && hi >= 3) ? d1.y : 0.f;
+        }
+        wacc_quad(a, d0, d1, r);
+      }
+      wacc_lane<NT>(a, tid, (float)P.tail.ic, &t1, &t2, &tx);
+    }
+    LDSP_DPP_GROUP8("v_max_f32_dpp", mx0, "v_max_f32_dpp", mx1, "v_max_f32_dpp", mx2, "v_min_f32_dpp", mn0, "v_min_f32_dpp", mn2, "v_add_f32_dpp", t1, "v_add_f32_dpp", t2, "v_add_f32_dpp", tx);
+    wave_argmax(bo_v, bo_i);
+    const unsigned long long bo = pack_vi(bo_v, bo_i);
+    if (lane == 63) {
+      S.wsum[(W_PZ + 0) * NW + wave] = t1; S.wsum[(W_PZ + 1) * NW + wave] = t2; S.wsum[(W_PZ + 2) * NW + wave] = tx;
+      atomicMax(&S.sl->fmx[FX_F0], ford(mx0));
+      atomicMax(&S.sl->fmx[FX_F1], ford(mx1));
+      atomicMax(&S.sl->fmx[FX_F2], ford(mx2));
+      atomicMax(&S.sl->fmx[FX_F0I], ford(-mn0));   // max(trap(-y)) = -min(trap(y))
+      atomicMax(&S.sl->fmx[FX_F2I], ford(-mn2));
+      atomicMax(&S.sl->vi[VI_OPT], bo);
+    }
+  }
+  __syncthreads();   // every read of T is done
+  STAMP(8); DSTOP(8);
+
+  // ------------------------------------------------------------------ phase 5: y -> X; Savitzky-Golay derivatives, current maxima
+#pragma unroll
+  for (int r = 0; r < R; ++r) *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = y[r];
+  if (tid < 64) S.X[Lp + tid] = 0.f;
+  __syncthreads();   // X = y visible to every wave
+  STAMP(9); DSTOP(9);
+  const int ng = L - P.sg_npts[0] + 1;
+  f4 g[R];   // SG(sg_npts[0]) output of the thread's quads (valid mode, trailing time axis); -inf beyond the output axis
+  {
+    // g[k] = sum_i c[i] y[k+i]: the four outputs of a quad from the M + 3 samples w[0 .. M+2] = the quad and its halo, one
+    // multiply-add per tap and output with the tap in a register (packed arithmetic on (even, odd) pairs needed every odd-aligned
+    // pair assembled by two moves and twice the registers for the taps: no fewer VALU cycles, 19 more VGPRs)
+    float gmax = -INFINITY;
+    float g_s1 = 0.f, g_s2 = 0.f;   // sums of the SG output over the baseline window (pivot 0: a derivative has no level)
+    float bv[4]; int bi[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { bv[f] = -INFINITY; bi[f] = 0x7fffffff; }
+    const int cw_from[4] = {P.cur_from[0], P.cur_from[1], P.cur_from[2], P.cur_from[3]};
+    const uint32_t cw_len[4] = {(uint32_t)(P.cur_until[0] - P.cur_from[0]), (uint32_t)(P.cur_until[1] - P.cur_from[1]),
+                                (uint32_t)(P.cur_until[2] - P.cur_from[2]), (uint32_t)(P.cur_until[3] - P.cur_from[3])};
+    auto track = [&](int f, int k, float gv) {
+      const float gw = ((uint32_t)(k - cw_from[f]) <= cw_len[f]) ? gv : -INFINITY;
+      const bool gt = gw > bv[f];
+      bv[f] = gt ? gw : bv[f];
+      bi[f] = gt ? k : bi[f];
+    };
+    float c0[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) c0[i] = P.sg_c[0][i];   // zero beyond the filter's own taps (the host zero-fills the block)
+    constexpr int NH = (M + 3 - 4 + 3) / 4;   // halo quads
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i0 = 4 * (tid + NT * r);
+      float wv_[4 + 4 * NH];
+      wv_[0] = y[r].x; wv_[1] = y[r].y; wv_[2] = y[r].z; wv_[3] = y[r].w;
+#pragma unroll
+      for (int j = 0; j < NH; ++j) {   // halo (runs past the trace into the zero margin: only masked outputs see that)
+        const f4 h = *reinterpret_cast<const f4*>(&S.X[i0 + 4 + 4 * j]);
+        wv_[4 + 4 * j] = h.x; wv_[5 + 4 * j] = h.y; wv_[6 + 4 * j] = h.z; wv_[7 + 4 * j] = h.w;
+      }
+      float go[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) go[e] = fmaf(c0[i], wv_[e + i], go[e]);
+      }
+      if (wrow(r) + 255 >= ng) {   // only the wave-row holding the end of the output axis
+#pragma unroll
+        for (int e = 0; e < 4; ++e) go[e] = (i0 + e < ng) ? go[e] : -INFINITY;
+      }
+      gmax = vmax3(vmax3(gmax, go[0], go[1]), go[2], go[3]);
+      g[r] = (f4){go[0], go[1], go[2], go[3]};
+      if (!row_out(cls_sgbl, r)) {   // sgbl.until <= ng-1: -inf never enters
+        float dd[4] = {go[0], go[1], go[2], go[3]};
+        if (!row_in(cls_sgbl, r)) {
+          const int lo = P.sgbl.from - i0, hi = P.sgbl.until - i0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dd[e] = (lo <= e && hi >= e) ? dd[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g_s1 += dd[e]; g_s2 = fmaf(dd[e], dd[e], g_s2); }
+      }
+      if (!row_out(cls_cur0, r)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) track(0, i0 + e, go[e]);
+      }
+      if (!row_out(cls_curx, r)) {   // SG(60 ns), SG(100 ns), plain derivative: only rows that touch the current window
+        float g1[4] = {0.f, 0.f, 0.f, 0.f}, g2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          const float c = P.sg_c[1][i];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g1[e] = fmaf(c, wv_[e + i], g1[e]);
+        }
+        if (!P.sg_same_02) {
+#pragma unroll
+          for (int i = 0; i < M; ++i) {
+            const float c = P.sg_c[2][i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g2[e] = fmaf(c, wv_[e + i], g2[e]);
+          }
+        }
+        const float ypv = (i0 > 0) ? S.X[i0 - 1] : 0.f;
+        float g3[4] = {y[r].x - ypv, y[r].y - y[r].x, y[r].z - y[r].y, y[r].w - y[r].z};   // y[k] - y[k-1]
+        if (i0 == 0) g3[0] = y[r].y - y[r].x;                                                // y[max(i,1)] - y[max(i-1,0)] at i = 0
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          track(1, i0 + e, g1[e]);
+          if (!P.sg_same_02) track(2, i0 + e, g2[e]);
+          track(3, i0 + e, g3[e]);
+        }
+      }
+    }
+    STAMP(10); DSTOP(10);
+    LDSP_DPP_GROUP3("v_add_f32_dpp", g_s1, "v_add_f32_dpp", g_s2, "v_max_f32_dpp", gmax);
+    if (lane == 63) {
+      S.wsum[(W_SGB + 0) * NW + wave] = g_s1; S.wsum[(W_SGB + 1) * NW + wave] = g_s2;
+      atomicMax(&S.sl->fmx[FX_G], ford(gmax));
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      if (f == 2 && P.sg_same_02) continue;
+      if (__ballot(bi[f] != 0x7fffffff) != 0ull) {
+        wave_argmax(bv[f], bi[f]);
+        if (lane == 63) atomicMax(&S.sl->vi[VI_CUR0 + f], pack_vi(bv[f], bi[f]));
+      }
+    }
+  }
+  // Confirmation of the five threshold candidates (see icpc_lean.hip): imin[q] = first QUAD with a sample at or above
+  // threshold q; lane q of every wave finds the sample, checks that it is not sample 0 and that the next tx_mintot - 1 samples
+  // stay at or above the threshold.  A trace that fails runs the general scan (bit-masks of y by ballot, run scan on the words).
+  // (The candidates were posted before the barriers of phase 3.)
+  int p_tx = 0x7fffffff;   // lane q < 5: first confirmed sample of threshold q
+  {
+    const int q = min(lane, 4);
+    const float thrq = e_max * ((q == 0) ? 0.1f : (q == 1) ? 0.5f : (q == 2) ? 0.8f : (q == 3) ? 0.9f : 0.99f);   // = thr_tx[q]
+    const int qd = S.sl->imin[IM_TX0 + q];
+    bool ok = e_max > 0.f;
+    if (ok && qd != 0x7fffffff) {
+      const f4 v = *reinterpret_cast<const f4*>(&S.X[4 * qd]);
+      const int e = (v.x >= thrq) ? 0 : (v.y >= thrq) ? 1 : (v.z >= thrq) ? 2 : 3;
+      p_tx = 4 * qd + e;
+      ok = p_tx >= 1 && p_tx + P.tx_mintot <= L;
+      for (int j = 1; ok && j < P.tx_mintot; ++j) ok = S.X[p_tx + j] >= thrq;
+    }
+    if (__ballot(lane < 5 && !ok) != 0ull) {   // block-uniform
+      __syncthreads();
+      if (tid < 5) S.sl->imin[IM_TX0 + tid] = 0x7fffffff;
+      for (int m = 0; m < SP; ++m) {
+        const float yv = S.X[tid + NT * m];
+#pragma unroll
+        for (int qq = 0; qq < 5; ++qq) {
+          const unsigned long long b = __ballot(yv >= e_max * ((qq == 0) ? 0.1f : (qq == 1) ? 0.5f : (qq == 2) ? 0.8f : (qq == 3) ? 0.9f : 0.99f));
+          if (lane == 0) *reinterpret_cast<unsigned long long*>(&S.bm[(M_FB + qq) * NWORDS + (NT >> 5) * m + 2 * wave]) = b;
+        }
+      }
+      __syncthreads();
+      for (int j = tid; j < 5 * NWORDS; j += NT) {
+        const int qq = j / NWORDS, wd = j % NWORDS;
+        int c, f;
+        intersect_word(S.bm + (M_FB + qq) * NWORDS, wd, NWORDS, P.tx_mintot, &c, &f);
+        if (c) atomicMin(&S.sl->imin[IM_TX0 + qq], f);
+      }
+      __syncthreads();
+      p_tx = S.sl->imin[IM_TX0 + q];
+    }
+  }
+  __syncthreads();
+  STAMP(11); DSTOP(11);
+  // filter f at output index k from y in LDS (the few samples the parabolas and crossing interpolations need)
+  auto flt_at = [&](int f, int k) -> float {
+    if (f < 3) {
+      float a[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) a[i] = S.X[k + i];
+      asm volatile("" ::: "memory");
+      float gq = 0.f;
+#pragma unroll
+      for (int i = 0; i < M; ++i) gq = fmaf(P.sg_c[f][i], (i < P.sg_npts[f]) ? a[i] : 0.f, gq);
+      return gq;
+    }
+    return S.X[max(k, 1)] - S.X[max(k - 1, 0)];
+  };
+  // in-trace pile-up threshold (dsp_routines.jl:75-77) and t50_current threshold (dsp_icpc.jl:192); their masks from the
+  // registers that hold the SG output (g = -inf beyond the output axis: bit 0)
+  float thr_intr, thr_sg50;
+  {
+    const float s1 = fold_partials<NW>(S.wsum + (W_SGB + 0) * NW, 0.f, [](float a, float b) { return a + b; });
+    const float s2 = fold_partials<NW>(S.wsum + (W_SGB + 1) * NW, 0.f, [](float a, float b) { return a + b; });
+    const float m_ = s1 * (float)P.sgbl.inv_n;
+    const float var_ = fmaxf(fmaf(s2, (float)P.sgbl.inv_n, -m_ * m_), 0.f);
+    thr_intr = __builtin_amdgcn_sqrtf(var_) * P.intrace_nsigma;
+    if (thr_intr == 0.f) thr_intr = 1.f;
+    thr_sg50 = ford_inv(S.sl->fmx[FX_G]) * 0.5f;
+    uint32_t wi[R], w5[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { wi[r] = s4_pack_word(nib_ge(g[r], thr_intr), lane); w5[r] = s4_pack_word(nib_ge(g[r], thr_sg50), lane); }
+    if ((lane & 7) == 7) {
+      uint32_t* bi_ = S.bm + M_INTR * NWORDS + 8 * wave + (lane >> 3);
+      uint32_t* b5_ = S.bm + M_SG50 * NWORDS + 8 * wave + (lane >> 3);
+#pragma unroll
+      for (int r = 0; r < R; ++r) { bi_[(NT / 8) * r] = wi[r]; b5_[(NT / 8) * r] = w5[r]; }
+    }
+  }
+  if (tid == (256 % NT)) {   // a lane of wave 4: signalstats of the pole-zero corrected tail
+    float s1 = 0.f, s2 = 0.f, sx = 0.f;
+    for (int ww = 0; ww < NW; ++ww) { s1 += S.wsum[(W_PZ + 0) * NW + ww]; s2 += S.wsum[(W_PZ + 1) * NW + ww]; sx += S.wsum[(W_PZ + 2) * NW + ww]; }
+    float tailmean, tailsigma, tailslope, tailoffset;
+    win_finish(s1, s2, sx, P.tail, S.misc[14], P.t_first, P.dt, &tailmean, &tailsigma, &tailslope, &tailoffset);
+    S.outv[C_tailmean] = tailmean; S.outv[C_tailsigma] = tailsigma; S.outv[C_tailslope] = tailslope; S.outv[C_tailoffset] = tailoffset;
+  }
+  if (tid == (384 % NT)) {   // a lane of wave 6: results of sweep B
+    float v; int i;
+    unpack_vi(S.sl->vi[VI_OPT], &v, &i);
+    S.outv[C_e_trap_max] = v; S.outv[C_t_trap_max] = P.t_first + P.dt * (float)(i + P.opt.flen - 1);
+    S.outv[C_e_10410] = ford_inv(S.sl->fmx[FX_F0]); S.outv[C_e_535] = ford_inv(S.sl->fmx[FX_F1]); S.outv[C_e_313] = ford_inv(S.sl->fmx[FX_F2]);
+    S.outv[C_e_10410_inv] = ford_inv(S.sl->fmx[FX_F0I]); S.outv[C_e_313_inv] = ford_inv(S.sl->fmx[FX_F2I]);   // trap(-y) = -trap(y)  (dsp_icpc.jl:199-204)
+  }
+  __syncthreads();   // the four masks are complete
+  STAMP(12); DSTOP(12);
+  // Intersect scans on the bit-masks (thread <-> word), see icpc_lean.hip
+  static_assert(2 * NWORDS == NT, "one t0 / inverted-t0 word per thread");
+  if (P.t0_mintot <= 97 && P.intrace_mintot <= 32) {   // block-uniform
+    const int q = tid / NWORDS, wd = tid % NWORDS;
+    const uint32_t* b0 = S.bm + (M_T0 + q) * NWORDS;
+    const bool has_i = tid < NWORDS;
+    const uint32_t* bi = S.bm + (has_i ? M_INTR : M_SG50) * NWORDS;
+    uint32_t t[5], u[3];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t[k] = b0[min(max(wd + k - 1, 0), NWORDS - 1)];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[k] = bi[min(max(wd + k - 1, 0), NWORDS - 1)];
+    asm volatile("" ::: "memory");
+    if (wd == 0) { t[0] = 0u; u[0] = 0u; }
+#pragma unroll
+    for (int k = 2; k < 5; ++k) t[k] = (wd + k - 1 < NWORDS) ? t[k] : 0u;
+    u[2] = (wd + 1 < NWORDS) ? u[2] : 0u;
+    int c, f;
+    intersect_pre(t[0], t[1], t[2], t[3], t[4], wd, P.t0_mintot, &c, &f);
+    if (c) { atomicAdd(&S.sl->isum[IS_T0 + q], c); atomicMin(&S.sl->imin[IM_T0 + q], f); }
+    if (has_i) {
+      intersect_rev_pre(u[0], u[1], u[2], wd, ng, P.intrace_mintot, &c, &f);
+      if (c) { atomicAdd(&S.sl->isum[IS_INTR], c); atomicMax(&S.sl->imax[0], f); }
+    } else {   // (tx_mintot <= 2 in this kernel)
+      intersect_pre(u[0], u[1], u[2], 0u, 0u, wd, P.tx_mintot, &c, &f);
+      if (c) atomicMin(&S.sl->imin[IM_SG50], f);
+    }
+  } else {
+    for (int wd = tid; wd < NWORDS; wd += NT) {
+      int c, f;
+      intersect_word(S.bm + M_SG50 * NWORDS, wd, NWORDS, P.tx_mintot, &c, &f);
+      if (c) atomicMin(&S.sl->imin[IM_SG50], f);
+    }
+    for (int j = tid; j < 2 * NWORDS; j += NT) {
+      const int q = j / NWORDS, wd = j % NWORDS;
+      int c, f;
+      intersect_word(S.bm + (M_T0 + q) * NWORDS, wd, NWORDS, P.t0_mintot, &c, &f);
+      if (c) { atomicAdd(&S.sl->isum[IS_T0 + q], c); atomicMin(&S.sl->imin[IM_T0 + q], f); }
+    }
+    for (int wd = tid; wd < NWORDS; wd += NT) {
+      int c, f;
+      intersect_word_rev(S.bm + M_INTR * NWORDS, wd, NWORDS, ng, P.intrace_mintot, &c, &f);
+      if (c) { atomicAdd(&S.sl->isum[IS_INTR], c); atomicMax(&S.sl->imax[0], f); }
+    }
+  }
+  __syncthreads();
+  STAMP(13); DSTOP(13);
+  // t50_current and the in-trace pile-up position: one wave (5, or the last), lanes 0..3 evaluate the four SG samples
+  if (wave == min(5, NW - 1)) {
+    const int intr_n = S.sl->isum[IS_INTR];
+    const int p = S.sl->imin[IM_SG50], e = S.sl->imax[0];
+    const bool has50 = p != 0x7fffffff;
+    const int at = (lane == 0) ? p - 1 : (lane == 1) ? p : (lane == 2) ? e + 1 : e;
+    float ev = 0.f;
+    if (lane < 4 && ((lane < 2) ? has50 : intr_n > 0)) ev = flt_at(0, at);
+    const float yl5 = __shfl(ev, 0), yh5 = __shfl(ev, 1), yli = __shfl(ev, 2), yhi = __shfl(ev, 3);
+    if (lane == 0) {
+      const float tg_first = P.t_first + P.dt * (float)(P.sg_npts[0] - 1);   // trailing alignment (A1)
+      float t50cur_us = 0.f, intr_x = NAN;
+      if (has50) t50cur_us = (tg_first + P.dt * ((float)(p - 1) + (thr_sg50 - yl5) / (yh5 - yl5))) * P.inv_unit_per_us;
+      if (intr_n > 0) {   // reversed index pos' = ng-1-e; r[pos'-1] = g[e+1], r[pos'] = g[e]
+        const int pr = ng - 1 - e;
+        const float xl = tg_first + P.dt * (float)(pr - 1);
+        const float xr_ = (thr_intr - yli) * P.dt / (yhi - yli) + xl;
+        intr_x = (tg_first + P.dt * (float)(ng - 1)) - xr_;   // last(time) - x   (dsp_routines.jl:81)
+      }
+      S.outv[C_t50_current] = t50cur_us; S.outv[C_inTrace_intersect] = intr_x; S.outv[C_inTrace_n] = __int_as_float(intr_n);
+    }
+  }
+  // crossing positions (sample units, split int + frac); NaN -> 0 us (dsp_routines.jl:24,41).  Seven interpolations, one per
+  // lane (q < 5: threshold q of y; 5: t0; 6: inverted t0), evaluated by every wave that uses a position.  The two values of the
+  // t0 trapezoid about its crossing are window sums of y (T has left the LDS): the wave sums the long leg once, at p - 1, and
+  // slides it by one sample.
+  Pos ptx1 = {0, 0.f}, ptx2 = {0, 0.f}, pt0 = {0, 0.f};
+  constexpr int W_CZWIN = 4 % NW;   // the wave that places the CUSP / ZAC estimator windows
+  if (wave <= 2 || wave == W_CZWIN || wave == NW - 1) {
+    const int q = min(lane, 6);
+    const int p = (q < 5) ? p_tx : S.sl->imin[q];
+    const bool has = (q < 5) ? p != 0x7fffffff : S.sl->isum[IS_T0 + q - 5] > 0;
+    const float frac = (q == 0) ? 0.1f : (q == 1) ? 0.5f : (q == 2) ? 0.8f : (q == 3) ? 0.9f : 0.99f;
+    const float thr = (q < 5) ? e_max * frac : P.t0_thr;
+    float tl = 0.f, th = 0.f;   // lanes 5, 6: the t0 trapezoid at p - 1 and p
+    if (wave == 1 % NW || wave == NW - 1) {   // the waves that use the t0 position (qdrift; the times)
+      const TrapDev t0 = P.t0;
+#pragma unroll
+      for (int qq = 5; qq < 7; ++qq) {
+        if (S.sl->isum[IS_T0 + qq - 5] <= 0) continue;   // (wave-uniform)
+        const int pp = S.sl->imin[qq] - 1;
+        const float a = wave_box(S.X, pp + t0.n1 + t0.g, t0.n2, lane);
+        const float b0 = (t0.n1 <= 3) ? 0.f : wave_box(S.X, pp, t0.n1, lane);
+        if (lane == qq) {
+          const float a1 = a + S.X[pp + t0.flen] - S.X[pp + t0.n1 + t0.g];
+          float bl_, bh_;
+          if (t0.n1 <= 3) {
+            const float y0_ = S.X[pp], y1_ = S.X[pp + 1], y2_ = S.X[pp + 2], y3_ = S.X[pp + 3];
+            bl_ = y0_ + ((t0.n1 >= 2) ? y1_ : 0.f) + ((t0.n1 >= 3) ? y2_ : 0.f);
+            bh_ = y1_ + ((t0.n1 >= 2) ? y2_ : 0.f) + ((t0.n1 >= 3) ? y3_ : 0.f);
+          } else {
+            bl_ = b0; bh_ = b0 + S.X[pp + t0.n1] - S.X[pp];
+          }
+          tl = a * t0.inv2 - bl_ * t0.inv1; th = a1 * t0.inv2 - bh_ * t0.inv1;
+          if (qq == 6) { tl = -tl; th = -th; }
+        }
+      }
+    }
+    Pos pp; pp.ip = 0; pp.fp = -P.t_first / P.dt;   // sample position of t = 0
+    float us = 0.f;
+    if (has) {
+      float yl, yh; int base;
+      if (q < 5) {
+        yl = S.X[p - 1]; yh = S.X[p]; base = p - 1;
+      } else {
+        yl = tl; yh = th;
+        base = p - 1 + (P.t0.flen - 1);   // trailing alignment (A1): back to input index space
+      }
+      pp.ip = base; pp.fp = (thr - yl) / (yh - yl);
+      us = (P.t_first + P.dt * ((float)base + pp.fp)) * P.inv_unit_per_us;
+    } else {
+      pp = pos_norm(pp);
+    }
+    ptx1.ip = __builtin_amdgcn_readlane(pp.ip, 1); ptx1.fp = readlane_f(pp.fp, 1);
+    ptx2.ip = __builtin_amdgcn_readlane(pp.ip, 2); ptx2.fp = readlane_f(pp.fp, 2);
+    pt0.ip = __builtin_amdgcn_readlane(pp.ip, 5); pt0.fp = readlane_f(pp.fp, 5);
+    if (wave == NW - 1) {
+      if (lane < 7) S.outv[lane == 0 ? C_t10 : lane == 1 ? C_t50 : lane == 2 ? C_t80 : lane == 3 ? C_t90 : lane == 4 ? C_t99 : lane == 5 ? C_t0 : C_t0_inv] = us;
+      const float t90 = readlane_f(us, 3), t0u = readlane_f(us, 5);
+      if (lane == 0) S.outv[C_drift_time] = (t90 - t0u) * P.unit_per_us;
+    }
+  }
+  STAMP(14); DSTOP(14);
+
+  // ------------------------------------------------------------------------------------ phase 6: signal estimators
+  {
+    lds_float* eslot = S.misc + 4;
+    if (wave == 0) {
+      // e_trap = SignalEstimator(trap_opt output, t50 + rt + ft/2)  (dsp_icpc.jl:163): lane l = window point l.  The trapezoid
+      // at the window's first point from two window sums of y, at the others by sliding both legs (prefix sums over the lanes of
+      // the samples entering and leaving).
+      Pos p = pos_add(ptx1, P.trap_pickoff);
+      p.ip -= (P.opt.flen - 1);
+      const int nsig = L - P.opt.flen + 1;
+      float v = NAN;
+      if (nsig >= P.sig_est.npts) {
+        const TrapDev fo = P.opt;
+        int i0; float u;
+        est_window(P.sig_est, p, nsig, &i0, &u);
+        float a = 0.f, b = 0.f;
+        for (int j = lane; j < fo.n2; j += 64) a += S.X[i0 + fo.n1 + fo.g + j];
+        for (int j = lane; j < fo.n1; j += 64) b += S.X[i0 + j];
+        float da = 0.f, db = 0.f;   // lane l >= 1: what the legs gain from point l - 1 to point l
+        if (lane >= 1 && lane < P.sig_est.npts) {
+          const int k = i0 + lane - 1;
+          da = S.X[k + fo.flen] - S.X[k + fo.n1 + fo.g];
+          db = S.X[k + fo.n1] - S.X[k];
+        }
+        LDSP_DPP_GROUP4("v_add_f32_dpp", a, "v_add_f32_dpp", b, "v_add_f32_dpp", da, "v_add_f32_dpp", db);
+        const float al = readlane_f(a, 63) + da, bl_ = readlane_f(b, 63) + db;
+        float t = 0.f;
+        if (lane < P.sig_est.npts) t = est_weight(P.sig_est, S.estB, lane, u) * (al * fo.inv2 - bl_ * fo.inv1);
+        v = wave_total(t);
+      }
+      if (lane == 0) eslot[0] = v;
+    }
+    if (wave == W_CZWIN) {
+      // windows of the CUSP / ZAC estimates (t50 + flt_length/2, dsp_icpc.jl:170,177) for the last phase
+      const int nout_c = L - P.cusp.Lf + 1, nout_z = L - P.zac.Lf + 1;
+      if (lane == 0) { S.misc[12] = 0.f; S.misc[13] = 0.f; }
+      if (nout_c >= P.sig_est.npts) {
+        Pos pc_ = pos_add(ptx1, P.cusp_pickoff);
+        pc_.ip -= (P.cusp.Lf - 1);
+        int i0c; float uc;
+        est_window(P.sig_est, pc_, nout_c, &i0c, &uc);
+        if (lane == 0) { S.misc[8] = __int_as_float(i0c); S.misc[9] = uc; S.misc[12] = S.X[i0c]; }
+      }
+      if (nout_z >= P.sig_est.npts) {
+        Pos pz2 = pos_add(ptx1, P.zac_pickoff);
+        pz2.ip -= (P.zac.Lf - 1);
+        int i0z; float uz;
+        est_window(P.sig_est, pz2, nout_z, &i0z, &uz);
+        if (lane == 0) { S.misc[10] = __int_as_float(i0z); S.misc[11] = uz; S.misc[13] = S.X[i0z]; }
+      }
+    }
+    if (wave == 1 % NW || wave == 2 % NW) {
+      const bool lq = (NW > 2) ? wave == 2 : false;
+      for (int pass = 0; pass < ((NW > 2) ? 1 : 2); ++pass) {
+        const bool is_lq = (NW > 2) ? lq : pass == 1;
+        const Pos base = is_lq ? ptx2 : pt0;
+        const float d1 = is_lq ? P.lq_d1 : P.qdrift_d1, d2 = is_lq ? P.lq_d2 : P.qdrift_d2;
+        const Pos p1 = pos_add(base, d1), p2 = pos_add(base, d2);
+        const int ips[3] = {base.ip, p1.ip, p2.ip};
+        const float fps[3] = {base.fp, p1.fp, p2.fp};
+        float* scr = (5 * NWORDS >= 1024) ? reinterpret_cast<float*>(S.bm + M_FB * NWORDS) + (is_lq ? 512 : 0) : nullptr;
+        const float res = qdrift_wave(P.int_est, S.estB + EST_TBL, S.X, L, ips, fps, scr);
+        if (lane == 0) eslot[is_lq ? 2 : 1] = res;
+      }
+    }
+    // get_wvf_maximum of the four current signals (src/interpolation.jl:30-46)
+    if (wave == min(3, NW - 1)) {
+      const int f = min(lane / 3, 3), d = lane - 3 * f - 1;
+      const int fs = (f == 2 && P.sg_same_02) ? 0 : f;
+      float v; int i;
+      unpack_vi(S.sl->vi[VI_CUR0 + fs], &v, &i);
+      const bool interior = i > P.cur_from[fs] && i < P.cur_until[fs];
+      float ev = 0.f;
+      if (lane < 12 && interior) ev = flt_at(fs, i + d);
+      const float em = __shfl(ev, 3 * f), e0 = __shfl(ev, 3 * f + 1), ep = __shfl(ev, 3 * f + 2);
+      if (interior) v = extrema3points(em, e0, ep);
+      if (lane < 12 && d == -1) S.outv[f == 0 ? C_a_sg : f == 1 ? C_a_60 : f == 2 ? C_a_100 : C_a_raw] = v;
+    }
+    STAMP(15); DSTOP(15);
+  }
+  // for the CUSP / ZAC stage (d[i] = y[i] - a*y[i-1], Dp = y - y[0] + eps*T): the first sample, the sample before each quad, and
+  // the sum of the wave-row's samples before the quad (T of a quad = wave-row offset + that)
+  const float y0 = S.X[0];
+  float yprev[R], p0[R];
+  {
+    float tin[R], tt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i0 = 4 * (tid + NT * r);
+      yprev[r] = (i0 > 0) ? S.X[i0 - 1] : 0.f;
+      const f2 t = y[r].xy + y[r].zw; tt[r] = t.x + t.y; tin[r] = tt[r];
+    }
+    LDSP_DPP_GROUP4("v_add_f32_dpp", tin[0], "v_add_f32_dpp", tin[1], "v_add_f32_dpp", tin[2], "v_add_f32_dpp", tin[3]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) p0[r] = tin[r] - tt[r];
+  }
+  {
+    lds_float* eslot = S.misc + 4;
+    __syncthreads();   // every read of X = y is done
+    if (tid == 0) {
+      S.outv[C_e_trap] = eslot[0];
+      S.outv[C_qdrift] = eslot[1];
+      S.outv[C_lq] = eslot[2];
+    }
+  }
+
+  // ------------------------------------------------------------------------------------ phase 7: CUSP / ZAC (dsp_icpc.jl:167-178)
+  // Closed form (CUSP / ZAC): with d[i] = y[i] - a*y[i-1],
+  //   out[k] = sc * ( sum_{j<=Lf-2} w[j] d[n-j] + w[Lf-1] y[k] ),  n = k+Lf-1,
+  // w = sinh flanks + flat top (+ parabolas for ZAC) splits into a causal one-pole G, an anti-causal one-pole A, the prefix sum
+  // Dp of d, and a double prefix sum of a sparse combination u of Dp; each is built in the S4 view, stored to X and read back
+  // lane-strided, two rows per step.  X takes them in turns:  Dp -> u -> PRF -> Dp -> G -> A  (ZAC), Dp -> G -> A (CUSP alone).
+  // y is still in the thread's registers (S4 view).
+  f4 ysave[SEP ? R : 1];
+  if constexpr (SEP) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) ysave[r] = y[r];
+  }
+  const f4 hq = *reinterpret_cast<const f4*>(&S.scn[R * NW + 4 * wave]), lq4 = *reinterpret_cast<const f4*>(&S.scn[2 * R * NW + 4 * wave]);
+  const float hwT[R] = {hq.x, hq.y, hq.z, hq.w}, lwT[R] = {lq4.x, lq4.y, lq4.z, lq4.w};
+  auto cz_pass = [&](auto wc_tag, auto wz_tag, const CuspZacDev& Z, const CuspZacDev& ZZ, const float cpiv) {
+    constexpr bool WC = decltype(wc_tag)::value, WZ = decltype(wz_tag)::value;
+    const int Lf = Z.Lf;
+    const int nout = L - Lf + 1, lt = Z.lt, f1 = Z.f1, ltp = Z.ltp;
+    const int pad = cz_pad_floats(Lf);
+    // Pivot (see icpc_lean.hip): the stage runs on y' = y - cpiv, cpiv = the level at the left edge of the pick-off window.
+    // y' is never materialised:  Dp' = Dp - eps*cpiv*i,  d' = d - eps*cpiv,  the taps on y[k] fold cpiv into their fma.
+    const float mec = -Z.eps * cpiv;
+    auto rd2 = [&](const float* p, int m) { return mk2(p[NT * m], p[NT * (m + 1)]); };
+    auto wr2 = [&](float* p, int m, f2 v) {
+      const uint32_t a = (uint32_t)(uintptr_t)(lds_float*)(p + NT * m);
+      asm volatile("ds_write2st64_b32 %0, %1, %2 offset1:%3" : : "v"(a), "v"(v.x), "v"(v.y), "n"(NT / 64) : "memory");
+    };
+    // ---- Dp'[i] = y[i] - y[0] + eps*T[i] + mec*i -> X (each thread its own quads; T rebuilt from the wave-row prefix)
+    auto store_dp = [&]() {
+      const f2 e2 = splat(Z.eps), y02 = splat(y0);
+      const float bf = (float)(4 * tid);
+      const f2 l01 = splat(mec) * mk2(bf, bf + 1.f), l23 = splat(mec) * mk2(bf + 2.f, bf + 3.f);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        f4 t = t_quad(y[r], p0[r], hwT[r], lwT[r]);
+        const f2 lr = splat(mec * (float)(4 * NT * r));
+        t.xy = fma2(e2, t.xy, y[r].xy - y02) + (l01 + lr);
+        t.zw = fma2(e2, t.zw, y[r].zw - y02) + (l23 + lr);
+        *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = t;
+      }
+    };
+    for (int i = tid; i < pad; i += NT) S.X[i - pad] = 0.f;   // the gap (dead mask words) becomes Dp[i < 0] = 0
+    if (tid < 64) S.X[Lp + tid] = 0.f;
+    store_dp();
+    __syncthreads();
+    STAMP(16); DSTOP(16);
+    f2 dz[SP / 2];   // ZAC - CUSP: the parabola part (+ the difference of the last taps)
+#pragma unroll
+    for (int m = 0; m < SP / 2; ++m) dz[m] = splat(0.f);
+    if constexpr (WZ) {
+      // ---- u[n] = sum_e zc_r[e] (Dp[n - s_e] - Dp[n - s_{e+1}])  (LS) -> X in place of Dp
+      {
+        f2 u[SP / 2];
+#pragma unroll
+        for (int m = 0; m < SP / 2; ++m) u[m] = splat(0.f);
+        if (ZZ.zc_n == 9) {   // (block-uniform) the usual tap structure: one chain, every shift read once, links unrolled
+          f2 prev[SP / 2];
+          {
+            const float* dp = &S.X[tid - ZZ.zc_s[0]];
+#pragma unroll
+            for (int m = 0; m < SP; m += 2) prev[m / 2] = rd2(dp, m);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const f2 ce = splat(ZZ.zc_r[e]);
+            const float* dq = &S.X[tid - ZZ.zc_s[e + 1]];
+#pragma unroll
+            for (int m = 0; m < SP; m += 2) {
+              const f2 cur = rd2(dq, m);
+              u[m / 2] = fma2(ce, prev[m / 2] - cur, u[m / 2]);
+              prev[m / 2] = cur;
+            }
+            pin(u[0]);
+          }
+        } else {
+          const int nz = ZZ.zu_n;
+          for (int e = 0; e < nz; ++e) {
+            const f2 ce = splat(ZZ.zu_coef[e]);
+            const float *dp = &S.X[tid - ZZ.zu_shift[e]], *dq = &S.X[tid - ZZ.zu_shift_b[e]];
+#pragma unroll
+            for (int m = 0; m < SP; m += 2) { u[m / 2] = fma2(ce, rd2(dp, m) - rd2(dq, m), u[m / 2]); pin(u[m / 2]); }
+          }
+        }
+        __syncthreads();   // every read of Dp is done
+#pragma unroll
+        for (int m = 0; m < SP; m += 2) wr2(&S.X[tid], m, u[m / 2]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the compiler does not count the stores of an asm statement)
+      }
+      __syncthreads();
+      STAMP(17); DSTOP(17);
+      // ---- PRF = cumsum(cumsum(u)) (S4).  Two levels: inside a wave-row (256 samples) the single and double running sums l1, l2
+      // start from zero and stay in float; the state entering each wave-row, (C1, C2), is carried in double:
+      //   c2[j] = C2 + (j+1)*C1 + l2[j],  C1' = C1 + l1[255],  C2' = C2 + 256*C1 + l2[255].   Each thread rewrites its own quads.
+      {
+        float ex1[R], ex2[R], i1[R], i2[R], p3[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const f4 uq = *reinterpret_cast<const f4*>(&S.X[4 * (tid + NT * r)]);
+          const float q0 = uq.x, q1_ = q0 + uq.y, q2_ = q1_ + uq.z;
+          p3[r] = q2_ + uq.w;
+          i1[r] = p3[r];
+          i2[r] = (q0 + q1_) + (q2_ + p3[r]);   // the quad's own contribution to the double sum
+        }
+        LDSP_DPP_GROUP4("v_add_f32_dpp", i1[0], "v_add_f32_dpp", i1[1], "v_add_f32_dpp", i1[2], "v_add_f32_dpp", i1[3]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { ex1[r] = i1[r] - p3[r]; i2[r] = fmaf(4.f, ex1[r], i2[r]); ex2[r] = i2[r]; }
+        LDSP_DPP_GROUP4("v_add_f32_dpp", i2[0], "v_add_f32_dpp", i2[1], "v_add_f32_dpp", i2[2], "v_add_f32_dpp", i2[3]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) ex2[r] = i2[r] - ex2[r];
+        double* pa = S.dpart; double* pb = S.dpart + R * NW;
+        if (lane == 63) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) { pa[r * NW + wave] = (double)i1[r]; pb[r * NW + wave] = (double)i2[r]; }
+        }
+        __syncthreads();
+        const double t1 = (lane < R * NW) ? pa[lane] : 0.0;
+        const double c1x = wave_incl_scan_sum_f64(t1) - t1;
+        const double t2 = (lane < R * NW) ? pb[lane] + 256.0 * c1x : 0.0;
+        const double c2x = wave_incl_scan_sum_f64(t2) - t2;
+        const float mrho = -ZZ.rho_sc;
+        const double jd0 = (double)(4 * lane + 1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const double C1 = readlane_d(c1x, r * NW + wave), C2 = readlane_d(c2x, r * NW + wave);
+          const double t = fma(C1, jd0, C2);
+          const float th = (float)t, tl = (float)(t - (double)th), c1f = (float)C1;
+          const f4 uq = *reinterpret_cast<const f4*>(&S.X[4 * (tid + NT * r)]);
+          float l1 = ex1[r], l2 = ex2[r];
+          f2 la, lb;
+          l1 += uq.x; l2 += l1; la.x = l2;
+          l1 += uq.y; l2 += l1; la.y = l2;
+          l1 += uq.z; l2 += l1; lb.x = l2;
+          l1 += uq.w; l2 += l1; lb.y = l2;
+          const f2 c2 = splat(c1f), t2_ = splat(tl), h2 = splat(th), m2 = splat(mrho);
+          const f2 va = m2 * (h2 + (t2_ + fma2(c2, mk2(0.f, 1.f), la))), vb = m2 * (h2 + (t2_ + fma2(c2, mk2(2.f, 3.f), lb)));
+          *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = (f4){va.x, va.y, vb.x, vb.y};
+        }
+      }
+      __syncthreads();
+      {
+        const float* pr = &S.X[tid + Lf - 1];
+#pragma unroll
+        for (int m = 0; m < SP; m += 2) { if (NT * m >= nout) continue; dz[m / 2] = rd2(pr, m); pin(dz[m / 2]); }
+      }
+      __syncthreads();   // every read of PRF is done
+      store_dp();
+      __syncthreads();
+      STAMP(18); DSTOP(18);
+    }
+    // ---- flat top + last tap (LS).  The last tap multiplies y'[k] = Dp'[k] + (y0 - cpiv) - eps T'[k]; the host admits this kernel
+    // only where eps * |w_last| * (rail * L) is far below the columns' resolution (dsp_icpc sets tau = 1e7 us "to switch off CR",
+    // src/dsp_icpc.jl:98: eps = 1.6e-9) and the third term is dropped.
+    f2 ac[SP / 2];
+    {
+      const f2 dwl = splat(ZZ.w_last - Z.w_last), wl = splat(Z.w_last), sc = splat(Z.sc);
+      const float yc = y0 - cpiv;
+      const f2 wlc = splat(Z.w_last * yc), dwlc = splat((ZZ.w_last - Z.w_last) * yc);
+      const float *dk = &S.X[tid], *dpa = &S.X[tid + Lf - 1 - lt], *dpb = &S.X[tid + Lf - 1 - f1];
+#pragma unroll
+      for (int m = 0; m < SP; m += 2) {
+        ac[m / 2] = splat(0.f);
+        if (NT * m >= nout) continue;   // row pair beyond the output range (block-uniform)
+        const f2 yk = rd2(dk, m), pa = rd2(dpa, m), pb = rd2(dpb, m);
+        ac[m / 2] = fma2(sc, pa - pb, fma2(wl, yk, wlc));
+        if constexpr (WZ) dz[m / 2] += fma2(dwl, yk, dwlc);
+        pin(ac[m / 2]);
+        if ((m & 2) == 2) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- d[i] = (y[i]-y[i-1]) + eps*y[i-1] for 1 <= i < L, else 0   (S4)
+    f2 d[R][2];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const f2 q0 = mk2(yprev[r], y[r].x), q1_ = mk2(y[r].y, y[r].z);
+      d[r][0] = fma2(splat(Z.eps), q0, (y[r].xy - q0) + splat(mec));
+      d[r][1] = fma2(splat(Z.eps), q1_, (y[r].zw - q1_) + splat(mec));
+      if (r == 0 && tid == 0) d[0][0].x = 0.f;
+    }
+    STAMP(19); DSTOP(19);
+    const float q1 = Z.qp1[1];
+    // ---- causal one-pole G -> X, rise(-) and fall(+) exponentials
+    {
+      float b[R], s_in[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float gq = d[r][0].x;
+        gq = fmaf(q1, gq, d[r][0].y);
+        gq = fmaf(q1, gq, d[r][1].x);
+        gq = fmaf(q1, gq, d[r][1].y);
+        b[r] = gq;
+      }
+      s4_exscan_affine_fwd<NT, R>(b, s_in, Z.qp4, Z.qpw, S.part);   // barrier inside: the LS reads of Dp are done
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float g0 = fmaf(q1, s_in[r], d[r][0].x), g1 = fmaf(q1, g0, d[r][0].y), g2 = fmaf(q1, g1, d[r][1].x), g3 = fmaf(q1, g2, d[r][1].y);
+        *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = (f4){g0, g1, g2, g3};
+      }
+    }
+    __syncthreads();
+    {
+      const float *gn = &S.X[tid + Lf - 1], *gnl = &S.X[tid + Lf - 1 - lt], *gk = &S.X[tid], *gkl = &S.X[tid + ltp - 1];
+      const f2 qlt = splat(Z.q_lt), qml = splat(Z.q_mltp), ql1 = splat(Z.q_ltp1), sh = splat(Z.sc_half_den);
+#pragma unroll
+      for (int m = 0; m < SP; m += 2) {
+        if (NT * m >= nout) continue;
+        const f2 pm = rd2(gn, m) - qlt * rd2(gnl, m);
+        const f2 fp = qml * (rd2(gkl, m) - ql1 * rd2(gk, m));
+        ac[m / 2] = fma2(sh, fp - pm, ac[m / 2]);
+        pin(ac[m / 2]);
+        if ((m & 2) == 2) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    STAMP(20); DSTOP(20);
+    // ---- anti-causal one-pole A -> X, rise(+) and fall(-) exponentials
+    {
+      float b[R], s_in[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float a = d[r][1].y;
+        a = fmaf(q1, a, d[r][1].x);
+        a = fmaf(q1, a, d[r][0].y);
+        a = fmaf(q1, a, d[r][0].x);
+        b[r] = a;
+      }
+      s4_exscan_affine_bwd<NT, R>(b, s_in, Z.qp4, Z.qpw, S.part + R * NW);   // barrier inside: the LS reads of G are done
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float a3 = fmaf(q1, s_in[r], d[r][1].y), a2 = fmaf(q1, a3, d[r][1].x), a1 = fmaf(q1, a2, d[r][0].y), a0 = fmaf(q1, a1, d[r][0].x);
+        *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = (f4){a0, a1, a2, a3};
+      }
+      if (tid == 0) S.X[Lp] = 0.f;   // A[L]
+    }
+    __syncthreads();
+    {
+      const float *a1 = &S.X[tid + Lf - lt], *a2 = &S.X[tid + Lf], *a3 = &S.X[tid + 1], *a4 = &S.X[tid + ltp];
+      const f2 qm1 = splat(Z.q_mlt1), qq1 = splat(Z.q1), qq2 = splat(Z.q2), ql1 = splat(Z.q_ltp1), sh = splat(Z.sc_half_den);
+#pragma unroll
+      for (int m = 0; m < SP; m += 2) {
+        if (NT * m >= nout) continue;
+        const f2 pp = qm1 * rd2(a1, m) - qq1 * rd2(a2, m);
+        const f2 fm = qq2 * (rd2(a3, m) - ql1 * rd2(a4, m));
+        ac[m / 2] = fma2(sh, pp - fm, ac[m / 2]);
+        if constexpr (WZ) dz[m / 2] += ac[m / 2];   // the ZAC output
+        pin(ac[m / 2]);
+        if ((m & 2) == 2) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    STAMP(21); DSTOP(21);
+    // ---- extremestats + SignalEstimator of both outputs (dsp_icpc.jl:170-171,177-178): value first, then its first index
+    float mxc = -INFINITY, mxz = -INFINITY;
+    float pc = 0.f, pz_ = 0.f;
+    float own_c, own_z;
+    {
+#pragma unroll
+      for (int m = 0; m < SP; m += 2) {
+        f2 a = ac[m / 2], z = dz[m / 2];
+        if (NT * (m + 2) > nout) {
+          const bool in0 = tid + NT * m < nout, in1 = tid + NT * (m + 1) < nout;
+          a.x = in0 ? a.x : -INFINITY; a.y = in1 ? a.y : -INFINITY; z.x = in0 ? z.x : -INFINITY; z.y = in1 ? z.y : -INFINITY;
+        }
+        mxc = vmax3(mxc, a.x, a.y); mxz = vmax3(mxz, z.x, z.y);
+      }
+      own_c = mxc; own_z = mxz;
+      if (nout >= P.sig_est.npts) {
+        const f4 ew = (f4){S.misc[8], S.misc[9], S.misc[10], S.misc[11]};   // i0 (bits) and u of the CUSP and of the ZAC estimate
+        const int i0c = __float_as_int(ew.x), i0z = __float_as_int(ew.z);
+        const int msc = (i0c - tid + NT - 1) / NT, msz = (i0z - tid + NT - 1) / NT;   // smallest m with tid + NT*m >= i0
+        const int lc = tid + NT * msc - i0c, lz = tid + NT * msz - i0z;
+        const bool inc_ = lc >= 0 && lc < P.sig_est.npts && msc >= 0 && msc < SP, inz = lz >= 0 && lz < P.sig_est.npts && msz >= 0 && msz < SP;
+        if (__ballot(inc_ || inz) != 0ull) {
+          float vc_ = 0.f, vz_ = 0.f;
+#pragma unroll
+          for (int m = 0; m < SP; ++m) {
+            vc_ = (m == msc) ? ((m & 1) ? ac[m / 2].y : ac[m / 2].x) : vc_;
+            vz_ = (m == msz) ? ((m & 1) ? dz[m / 2].y : dz[m / 2].x) : vz_;
+          }
+          if (inc_) pc = est_weight(P.sig_est, S.estB, lc, ew.y) * vc_;
+          if (inz) pz_ = est_weight(P.sig_est, S.estB, lz, ew.w) * vz_;
+        }
+      }
+      LDSP_DPP_GROUP4("v_add_f32_dpp", pc, "v_add_f32_dpp", pz_, "v_max_f32_dpp", mxc, "v_max_f32_dpp", mxz);
+      if (lane == 63) {
+        if (WC) { S.wsum[(W_CZ + 0) * NW + wave] = pc; atomicMax(&S.sl->fmx[FX_CUSP], ford(mxc)); }
+        if (WZ) { S.wsum[(W_CZ + 1) * NW + wave] = pz_; atomicMax(&S.sl->fmx[FX_ZAC], ford(mxz)); }
+      }
+    }
+    __syncthreads();
+    {
+      const float vc = ford_inv(S.sl->fmx[FX_CUSP]), vz = ford_inv(S.sl->fmx[FX_ZAC]);
+      if (__ballot((WC && own_c == vc) || (WZ && own_z == vz)) != 0ull) {   // only the waves that hold a maximum look its index up
+        int bc = 0x7fffffff, bz = 0x7fffffff;
+#pragma unroll
+        for (int m = SP - 1; m >= 0; --m) {   // findmax: first occurrence
+          const float a = (m & 1) ? ac[m / 2].y : ac[m / 2].x, z = (m & 1) ? dz[m / 2].y : dz[m / 2].x;
+          const bool in = tid + NT * m < nout;
+          bc = (in && a == vc) ? tid + NT * m : bc;
+          bz = (in && z == vz) ? tid + NT * m : bz;
+        }
+        if (WC && bc != 0x7fffffff) atomicMin(&S.sl->imin[IM_CUSP], bc);
+        if (WZ && bz != 0x7fffffff) atomicMin(&S.sl->imin[IM_ZAC], bz);
+      }
+    }
+    STAMP(22); DSTOP(22);
+    __syncthreads();
+    if (tid < 2 && (tid == 0 ? WC : WZ)) {
+      const int f = tid;
+      float s = 0.f;
+      for (int ww = 0; ww < NW; ++ww) s += S.wsum[(W_CZ + f) * NW + ww];
+      const float v = ford_inv(S.sl->fmx[f ? FX_ZAC : FX_CUSP]);
+      const int i = S.sl->imin[f ? IM_ZAC : IM_CUSP];
+      const double back = (double)cpiv * (f ? ZZ.hsum : Z.hsum);   // the pivot's share of the output (estimator weights sum to one)
+      S.outv[f ? C_e_zac : C_e_cusp] = (nout >= P.sig_est.npts) ? (float)((double)s + back) : NAN;
+      S.outv[f ? C_e_zac_max : C_e_cusp_max] = (float)((double)v + back);
+      S.outv[f ? C_t_zac_max : C_t_cusp_max] = P.t_first + P.dt * (float)(i + Lf - 1);
+    }
+  };
+  using T_ = std::true_type; using F_ = std::false_type;
+  if constexpr (!SEP) {
+    cz_pass(T_{}, T_{}, P.cusp, P.zac, S.misc[12]);
+  } else {
+    const float cp_c = S.misc[12], cp_z = S.misc[13];
+    cz_pass(T_{}, F_{}, P.cusp, P.zac, cp_c);
+    __syncthreads();   // every read of A is done
+#pragma unroll
+    for (int r = 0; r < R; ++r) y[r] = ysave[r];
+    cz_pass(F_{}, T_{}, P.zac, P.zac, cp_z);
+  }
+  STAMP(23); DSTOP(23);
+  // ------------------------------------------------------------------------------------------------ outputs
+  __syncthreads();   // the output row was filled by lanes of different waves
+  static_assert(C_NCOLS <= 64, "the output row is stored by wave 0");
+  if (tid < C_NCOLS) {
+    float* dst = reinterpret_cast<float*>(out.col[tid]);
+    if (dst) dst[(size_t)blockIdx.x * (size_t)out.stride] = S.outv[tid];
+  }
+}
+
+template <int NT, int M, bool SEP>
+static hipError_t launch_t(const float* wf, int64_t n, const IcpcDev* dP, const IcpcOutDev& out, const float* ext_bl, float ext_bl_scale,
+                           int Lf, hipStream_t st) {
+  const size_t smem = Smem<NT>::bytes(cz_pad_floats(Lf)) + (size_t)g_dbg_lds_pad;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_lean3_kernel<NT, M, SEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((icpc_lean3_kernel<NT, M, SEP>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, out, ext_bl, ext_bl_scale);
+  return hipGetLastError();
+}
+
+}  // namespace lean3
+
+// LDS bytes of the kernel for a tile of NT threads and CUSP/ZAC filters of Lf taps
+size_t icpc_lean3_smem_bytes(int NT, int Lf) {
+  switch (NT) {
+    case 64: return lean3::Smem<64>::bytes(lean3::cz_pad_floats(Lf));
+    case 128: return lean3::Smem<128>::bytes(lean3::cz_pad_floats(Lf));
+    case 256: return lean3::Smem<256>::bytes(lean3::cz_pad_floats(Lf));
+    case 512: return lean3::Smem<512>::bytes(lean3::cz_pad_floats(Lf));
+    default: return (size_t)-1;
+  }
+}
+
+// sg_slots: 7 or 13 (the smallest that holds the three Savitzky-Golay windows)
+hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, const IcpcDev* dP, const IcpcOutDev& out,
+                             const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st) {
+#ifdef LDSP_DEV_512
+#define LDSP_LEAN_CASES LDSP_CASE(512)
+#else
+#define LDSP_LEAN_CASES LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512)
+#endif
+#define LDSP_CASE(N) \
+  case N: return cz_shared ? (sg_slots <= 7 ? lean3::launch_t<N, 7, false>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st) : lean3::launch_t<N, 13, false>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st)) \
+                           : (sg_slots <= 7 ? lean3::launch_t<N, 7, true>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st) : lean3::launch_t<N, 13, true>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st));
+  switch (NT) {
+    LDSP_LEAN_CASES
+    default: return hipErrorInvalidValue;
+  }
+#undef LDSP_CASE
+}
+
+}  // namespace ldsp

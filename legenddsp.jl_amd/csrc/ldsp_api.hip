@@ -22,6 +22,10 @@ hipError_t launch_icpc(const float* wf, int64_t n, int NT, int R, bool full, con
 hipError_t launch_icpc_lean(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, const IcpcDev* dP, const IcpcOutDev& out,
                             const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st);
 size_t icpc_lean_smem_bytes(int NT, int Lf);
+hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, const IcpcDev* dP, const IcpcOutDev& out,
+                             const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st);
+size_t icpc_lean3_smem_bytes(int NT, int Lf);
+extern int g_dbg_lds_pad;
 hipError_t launch_pz_trap_lean(const float* wf, int64_t n, int NT, bool u16, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 size_t icpc_smem_bytes(int NT);
@@ -146,6 +150,9 @@ int ldsp_ctx_set_option(ldsp_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "two_kernel")) { c->two_kernel = value != 0; return LDSP_OK; }
   if (!strcmp(key, "sipm_generic")) { c->sipm_generic = value != 0; return LDSP_OK; }
   if (!strcmp(key, "dbg_stop")) { c->dbg_stop = (int)value; c->icpc_valid = false; return LDSP_OK; }
+  if (!strcmp(key, "dbg_lds_pad")) { ldsp::g_dbg_lds_pad = (int)value; return LDSP_OK; }
+  if (!strcmp(key, "icpc_lean2")) { c->icpc_lean2 = value != 0; return LDSP_OK; }
+  if (!strcmp(key, "icpc_lean3")) { c->icpc_lean3 = value != 0; return LDSP_OK; }
   if (!strcmp(key, "icpc_generic")) { c->icpc_generic = value != 0; return LDSP_OK; }
   if (!strcmp(key, "icpc_r2")) { c->icpc_r2 = value != 0; c->icpc_valid = false; return LDSP_OK; }
   if (!strcmp(key, "dbg_stamps")) { c->dbg_stamps = reinterpret_cast<long long*>((uintptr_t)value); c->icpc_valid = false; return LDSP_OK; }
@@ -416,6 +423,19 @@ static bool icpc_lean_applies(const ldsp_ctx* c) {
          icpc_lean_smem_bytes(H.NT, std::max(H.cusp.Lf, H.zac.Lf)) <= 80640;   // two traces per CU (160 KiB LDS, 1280-byte granules)
 }
 
+// icpc_lean3.hip (one trace-sized LDS array, three workgroups per CU) takes what the round-2 lean kernel takes, for tiles of up to
+// 512 threads, where the last tap's eps * T term it drops is far below the columns' resolution (|w_last| * eps * rail * L < 1e-2 on a
+// trace that sits at the rail, a hundredth of that on a real one;
+// dsp_icpc sets the filters' tau to 1e7 us, src/dsp_icpc.jl:98: 1.4e-3 for a 16-bit rail and 8192 samples).  Option "icpc_lean2"
+// selects the round-2 kernel (comparator).
+static bool icpc_lean3_applies(const ldsp_ctx* c) {
+  const IcpcDev& H = c->icpc_host;
+  if (!c->icpc_lean3 || c->icpc_lean2 || !icpc_lean_applies(c) || H.NT > 512) return false;
+  const double rail = std::max(std::fabs((double)H.sat_high), std::fabs((double)H.sat_low)) * (double)H.L;
+  const double drop = std::max(std::fabs((double)H.cusp.w_last) * H.cusp.eps, std::fabs((double)H.zac.w_last) * H.zac.eps) * rail;
+  return drop < 1e-2 && icpc_lean3_smem_bytes(H.NT, std::max(H.cusp.Lf, H.zac.Lf)) <= 80640;
+}
+
 static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p, int in_u16 = 0) {
   if (c->icpc_valid && c->icpc_mode_built == c->cusp_direct && c->icpc_u16_built == in_u16 && !memcmp(&c->icpc_last, p, sizeof *p)) return LDSP_OK;
   std::vector<float> hc, hz;
@@ -484,6 +504,12 @@ int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_
   const IcpcDev& H = c->icpc_host;
   const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
   const bool lean_ok = icpc_lean_applies(c) && !main_only;
+  if (lean_ok && icpc_lean3_applies(c)) {
+    HIP_TRY(launch_icpc_lean3(wf, n, H.NT, sg_max, H.cz_shared != 0, c->d_icpc, od, ext_bl, ext_bl_scale, std::max(H.cusp.Lf, H.zac.Lf), c->stream));
+    c->last_kernel = "lean3::icpc_lean3_kernel";
+    if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
+    return LDSP_OK;
+  }
   if (lean_ok) {
     HIP_TRY(launch_icpc_lean(wf, n, H.NT, sg_max, H.cz_shared != 0, c->d_icpc, od, ext_bl, ext_bl_scale, std::max(H.cusp.Lf, H.zac.Lf), c->stream));
     c->last_kernel = "lean::icpc_lean_kernel";

@@ -8,11 +8,14 @@ import numpy as np
 import torch
 import legenddsp_jl_amd as ldsp
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+n = int(sys.argv[1]) if len(sys.argv) > 1 and "=" not in sys.argv[1] else 65536
+opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)   # context options, e.g. dbg_lds_pad=60000 (one workgroup per CU)
 L, NW, SLOTS, BLOCKS = 8192, 8, 32, 2048
 params = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, L, 0.0, 16.0)
 wf = ldsp.synth.hpge_batch(n, L, device="cuda")
 ctx = ldsp.Context(0)
+for k, v in opts.items():
+    ctx.set_option(k, int(v))
 buf = torch.zeros((BLOCKS, 16, SLOTS), dtype=torch.int64, device="cuda")
 out = torch.empty((n, 48), dtype=torch.float32, device="cuda")
 ldsp.icpc_run(wf, params, ctx, out=out)          # warm-up without stamps
@@ -33,7 +36,15 @@ lean = {0: "start", 1: "load, raw extremes, baseline sums", 2: "per-wave partial
         14: "threshold confirmation, crossings", 15: "estimators, parabolas (waves 0-3), to the barrier", 16: "barrier, CZ: Dp, d (+barrier)",
         17: "CZ: flat top + ZAC taps (summed by parts)", 18: "CZ: causal scan + readback", 19: "CZ: anti-causal scan + readback",
         20: "CZ: double cumsum + readback", 21: "CZ: maxima, estimator points", 22: "CZ: collect"}
-names = lean if "lean" in ctx.last_kernel_name() else generic
+lean3 = {0: "start", 1: "load, raw extremes, baseline sums", 2: "per-wave partials + barrier", 3: "blmean, shift, tail sums, cumsum scan + barrier",
+         4: "pz offsets (wave 0) + barrier, pole-zero", 5: "threshold candidates, T scan (wave 0), T -> X + 3 barriers", 6: "sweep A (S4: t0 masks)",
+         7: "sweep B (4 trapezoids)", 8: "tail sums, sweep reductions + barrier", 9: "y -> X + barrier", 10: "SG pass (S4)",
+         11: "SG reductions, threshold confirmation + barrier", 12: "SG masks from registers, finishing lanes + barrier", 13: "run scans on the masks + barrier",
+         14: "t50_current / pile-up position, crossings", 15: "estimators, parabolas (waves 0-3)", 16: "yprev, p0, barrier, CZ: Dp -> X + barrier",
+         17: "CZ: u (ZAC taps) -> X + 2 barriers", 18: "CZ: double cumsum -> X, readback, Dp -> X + 4 barriers", 19: "CZ: flat top, d",
+         20: "CZ: causal scan + readback", 21: "CZ: anti-causal scan + readback", 22: "CZ: maxima, estimator points", 23: "CZ: collect"}
+kn = ctx.last_kernel_name()
+names = lean3 if "lean3" in kn else lean if "lean" in kn else generic
 print("kernel:", ctx.last_kernel_name())
 ids = sorted(names)
 valid = (s[:, :, ids] > 0).all(axis=(1, 2))
