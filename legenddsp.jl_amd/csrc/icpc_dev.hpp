@@ -60,6 +60,12 @@ struct CuspZacDev {
   int32_t zc_n;          // number of shifts (links = zc_n - 1)
   int32_t zc_s[13];
   float zc_r[12];
+  // the same chain with the parabola's LAST tap folded in (icpc_lean3.hip, CUSP and ZAC sharing their geometry): that tap multiplies
+  // y[k] = Dp[k] + const directly; as a term of the double prefix sum it is par[Lf-1] * (Dp[n-Lf+1] - 2 Dp[n-Lf] + Dp[n-Lf-1]),
+  // three more taps at shifts the chain already has or next to them.  The constant goes to the result: wl_fold * (y[0] - pivot)
+  int32_t zf_n;
+  int32_t zf_s[13];
+  float zf_r[12];
   // sum of the direct-form taps: the filter's response to a constant level.  The closed form runs on y - c (c = the level at
   // the left edge of the pick-off window) and adds c * hsum back at the end, see cz_body / icpc_lean.hip phase 7
   double hsum;

@@ -12,8 +12,8 @@
 //     (ds_read_b128 / 2 x b64 / b32 + b64 + b32 by the shift's alignment: tools/micro/lds_s4shift_test.hip);
 //   * the Savitzky-Golay output never goes to LDS: the pile-up and half-maximum masks are built from the registers that hold
 //     it (four predicate bits per thread, eight lanes OR-ed into a word by three DPP steps);
-//   * CUSP / ZAC: the parabola part (u -> double prefix sum -> PRF) is finished BEFORE the flat top and the two one-pole
-//     recursions start, so that at most three 16-sample register arrays are live at any time.
+//   * CUSP / ZAC: the chain of ZAC taps runs in two halves of the rows, the double prefix sum re-reads its own quads, and the
+//     parabola kernel's last tap is folded into that chain: at most three 16-sample register arrays are live at any time.
 // Same phases, same summation rules and the same 48 columns as the round-2 kernel; every other parameter set runs icpc_kernel.
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -146,7 +146,7 @@ template <int NT>
 struct Smem {
   static constexpr int NW = NT / 64, Lp = NT * SP, NWORDS = Lp / 32;
   static constexpr int NSMALL = 2 * R * NW /*part*/ + 3 * R * NW /*scn*/ + 5 * NW /*wred*/ + NWSUM * NW /*wsum*/ + C_NCOLS + 32 /*outv, misc*/ +
-                                2 * EST_TBL + 2 * (R * NW + 1) /*hy*/;
+                                2 * EST_TBL + (4 * 3 + 1) * (R * NW + 1) /*hy: up to 3 halo quads + the last sample per wave-row*/;
   uint32_t* bm;    // [NMASKROWS][NWORDS] in the gap in front of X
   float* X;        // [Lp + 64]
   double* dpart;   // [2][R*NW]  double prefix sum of the ZAC parabolas
@@ -154,7 +154,8 @@ struct Smem {
   float* part;     // [2][R*NW]  wave-row totals of the block scans (alternating buffers)
   float* scn;      // [3][R*NW]  what wave 0 makes of them (pz offsets; T offsets hi, lo)
   float* estB;     // [2][EST_TBL]
-  float* hy;       // [R*NW + 1][2]  first two samples of y of every wave-row (time order), then zeros: the halo of a wave's lane 63
+  float* hy;       // [R*NW + 1][NH] first NH quads of y of every wave-row (time order; the last entry: zeros) = the halo of a wave's
+                   // last lanes; then [R*NW + 1]: the last sample of the wave-row BEFORE wave-row j
   lds_float* wred;     // [5][NW]    phase-1 per-wave partials: s1, s2, sx, max, min
   lds_float* wsum;     // [NWSUM][NW]
   lds_float* outv;     // [C_NCOLS]
@@ -175,7 +176,7 @@ struct Smem {
     scn = part + 2 * R * NW;
     estB = scn + 3 * R * NW;
     hy = estB + 2 * EST_TBL;
-    float* wred_ = hy + 2 * (R * NW + 1);
+    float* wred_ = hy + (4 * 3 + 1) * (R * NW + 1);
     lds_float* base = (lds_float*)wred_;
     asm volatile("" : "+v"(base));   // one VGPR base for the small arrays (they lie beyond the reach of a zero-based immediate)
     wred = base;
@@ -256,6 +257,18 @@ __device__ __forceinline__ f4 t_quad(f4 y, float p0, float hw, float lw) {
 // a thread's quad of a LINEAR LDS array at an arbitrary index (al = idx & 3, block-uniform): the widest reads the alignment
 // allows (a 4-byte-aligned ds_read_b64 is 19x slower than an aligned one, two ds_read2_b32 of adjacent words 5x:
 // tools/micro/lds_b64_test.hip, lds_s4shift_test.hip)
+template <int AL>   // AL = the index's alignment class: 0 (multiple of 4), 2 (even), 1 (odd)
+__device__ __forceinline__ f4 rdq_t(const float* X, int idx) {
+  if constexpr (AL == 0) return *reinterpret_cast<const f4*>(&X[idx]);
+  if constexpr (AL == 2) {
+    const f2 a = *reinterpret_cast<const f2*>(&X[idx]), b = *reinterpret_cast<const f2*>(&X[idx + 2]);
+    return (f4){a.x, a.y, b.x, b.y};
+  }
+  const float a = X[idx];
+  const f2 m = *reinterpret_cast<const f2*>(&X[idx + 1]);
+  const float d = X[idx + 3];
+  return (f4){a, m.x, m.y, d};
+}
 __device__ __forceinline__ f4 rdq(const float* X, int idx, int al) {
   if (al == 0) return *reinterpret_cast<const f4*>(&X[idx]);
   if (al == 2) {
@@ -276,6 +289,9 @@ __device__ __forceinline__ uint32_t s4_pack_word(uint32_t nib, int lane) {
   v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
   return v;
 }
+// the thread index as a value hipcc cannot connect to its other copies: index arithmetic (4 (tid + NT r) + e, window-edge tests ..) is
+// recomputed in each phase — one VALU each — instead of living in a dozen registers from the first phase to the last
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ uint32_t nib_ge(f4 v, float t) {
   return (uint32_t)(v.x >= t) | ((uint32_t)(v.y >= t) << 1) | ((uint32_t)(v.z >= t) << 2) | ((uint32_t)(v.w >= t) << 3);
 }
@@ -335,9 +351,19 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     reinterpret_cast<uint32_t*>(S.sl)[tid] = init;
   }
   if (tid < 64) S.X[Lp + tid] = 0.f;
-  if (tid < 2) S.hy[2 * R * NW + tid] = 0.f;
 
-  // ---------------------------------------------------------------------------------- phase 1: raw extremes, baseline sums
+  // ================================================================== round 1: one pass over the raw trace in registers
+  // Everything the chain needs before the first filter is linear in the baseline: with the pivot pv = the baseline window's first
+  // sample (known at load time), x' = raw - pv and delta = blmean - pv,
+  //   shift_waveform      x[i]  = x'[i] - delta                                                     (dsp_icpc.jl:105)
+  //   InvCRFilter         y[i]  = x[i] + c cs[i],      cs[i] = cs'[i] - delta (i+1)                  (dsp_icpc.jl:119-120)
+  //   its prefix sum      T[i]  = E1'[i] + c E2'[i] - delta (i + c i (i+1) / 2)                      (what the trapezoids read)
+  // where cs' = cumsum(x') (inclusive), E1' its exclusive form and E2'[i] = sum_{m<i} cs'[m].  So the baseline sums, the raw
+  // extremes and the single and double prefix sums of x' inside every wave-row (256 samples) come out of ONE group of DPP scans
+  // and ONE exchange of per-wave partials; one wave turns the wave-row totals into the state entering each wave-row (in double:
+  // C1 = cs' before the row, C2 = E2' at its first sample), and y and T follow directly — in place of three exchanges (baseline;
+  // cumsum for the pole-zero; prefix sum of y) with a serial section each.
+  float ex1[R], ex2[R];   // sums of x' / of cs' (row-local) over the samples of the wave-row before this lane's quad
   {
     float rmax = vmax3(x[0].x, x[0].y, x[0].z), rmin = vmin3(x[0].x, x[0].y, x[0].z);
     rmax = vmax3(rmax, x[0].w, x[1].x); rmin = vmin3(rmin, x[0].w, x[1].x);
@@ -349,12 +375,17 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     rmax = vmax(rmax, x[3].w); rmin = vmin(rmin, x[3].w);
     WAcc a = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
     const f2 pv = splat(pv_bl);
+    float t[R], q2[R], i1[R], i2[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+      x[r].xy -= pv; x[r].zw -= pv;
+      const float c0 = x[r].x, c1 = c0 + x[r].y, c2 = c1 + x[r].z, c3 = c2 + x[r].w;
+      t[r] = c3; i1[r] = c3;
+      q2[r] = (c0 + c1) + (c2 + c3);   // the quad's own part of the double sum
       if (row_out(cls_bl, r)) continue;
-      f2 d0 = x[r].xy - pv, d1 = x[r].zw - pv;
+      f2 d0 = x[r].xy, d1 = x[r].zw;
       if (!row_in(cls_bl, r)) {
-        const int lo = P.bl.from - 4 * (tid + NT * r), hi = P.bl.until - 4 * (tid + NT * r);   // in-window e in [lo, hi]
+        const int i0 = 4 * (opaque(tid) + NT * r), lo = P.bl.from - i0, hi = P.bl.until - i0;   // in-window e in [lo, hi]
         d0.x = (lo <= 0 && hi >= 0) ? d0.x : 0.f; d0.y = (lo <= 1 && hi >= 1) ? d0.y : 0.f;
         d1.x = (lo <= 2 && hi >= 2) ? d1.x : 0.f; d1.y = (lo <= 3 && hi >= 3) ? d1.y : 0.f;
       }
@@ -363,50 +394,78 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     float s1, s2, sx;
     wacc_lane<NT>(a, tid, (float)P.bl.ic, &s1, &s2, &sx);
     LDSP_DPP_GROUP5("v_add_f32_dpp", s1, "v_add_f32_dpp", s2, "v_add_f32_dpp", sx, "v_max_f32_dpp", rmax, "v_min_f32_dpp", rmin);
+    LDSP_DPP_GROUP4("v_add_f32_dpp", i1[0], "v_add_f32_dpp", i1[1], "v_add_f32_dpp", i1[2], "v_add_f32_dpp", i1[3]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ex1[r] = i1[r] - t[r]; i2[r] = fmaf(4.f, ex1[r], q2[r]); ex2[r] = i2[r]; }
+    LDSP_DPP_GROUP4("v_add_f32_dpp", i2[0], "v_add_f32_dpp", i2[1], "v_add_f32_dpp", i2[2], "v_add_f32_dpp", i2[3]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) ex2[r] = i2[r] - ex2[r];
     if (lane == 63) {
       S.wred[0 * NW + wave] = s1; S.wred[1 * NW + wave] = s2; S.wred[2 * NW + wave] = sx;
       S.wred[3 * NW + wave] = rmax; S.wred[4 * NW + wave] = rmin;
+      *reinterpret_cast<f4*>(&S.part[4 * wave]) = (f4){i1[0], i1[1], i1[2], i1[3]};            // [wave][r]
+      *reinterpret_cast<f4*>(&S.part[R * NW + 4 * wave]) = (f4){i2[0], i2[1], i2[2], i2[3]};
     }
   }
   STAMP(1); DSTOP(1);
   __syncthreads();
-  float blmean, raw_max, raw_min;
+  if (wave == 0) {   // state entering each wave-row, lane j <-> wave-row j in time order (r = j / NW, w = j % NW)
+    const int jr = lane / NW, jw = lane - jr * NW;
+    const bool in = lane < R * NW;
+    // C1_j = sum_{j'<j} S_j',  C2_j = sum_{j'<j} (Q_j' + 256 C1_j') = sum_{j'<j} Q_j' + 256 ((j-1) sum_{j'<j} S_j' - sum_{j'<j} j' S_j'):
+    // three INDEPENDENT scans (their DPP steps interleave) instead of two dependent ones
+    const double sv = in ? (double)S.part[4 * jw + jr] : 0.0, qv = in ? (double)S.part[R * NW + 4 * jw + jr] : 0.0, jv = sv * (double)lane;
+    const double c1i = wave_incl_scan_sum_f64(sv), qi = wave_incl_scan_sum_f64(qv), ji = wave_incl_scan_sum_f64(jv);
+    const double c1x = c1i - sv;
+    const double c2x = (qi - qv) + 256.0 * ((double)(lane - 1) * c1x - (ji - jv));
+    const double c2i = qi + 256.0 * ((double)lane * c1i - ji);   // (at lane R*NW - 1: the state after the last wave-row)
+    const double A = fma(P.pz_c64, c2x, c1x);   // T at the row's first sample, but for the delta terms
+    const float hi = (float)A;
+    if (in) { S.scn[4 * jw + jr] = hi; S.scn[R * NW + 4 * jw + jr] = (float)(A - (double)hi); S.scn[2 * R * NW + 4 * jw + jr] = (float)(P.pz_c64 * c1x); }
+    const double At = fma(P.pz_c64, readlane_d(c2i, R * NW - 1), readlane_d(c1i, R * NW - 1));   // ... at sample L
+    if (lane == 0) { const float ah = (float)At; S.misc[16] = ah; S.misc[17] = (float)(At - (double)ah); }
+  }
+  float blmean, raw_max, raw_min, delta;
   {
     const float s = fold_partials<NW>(S.wred, 0.f, [](float a, float b) { return a + b; });
     const float mx = fold_partials<NW>(S.wred + 3 * NW, -INFINITY, [](float a, float b) { return vmax(a, b); });
     const float mn = fold_partials<NW>(S.wred + 4 * NW, INFINITY, [](float a, float b) { return vmin(a, b); });
-    blmean = fmaf(s, (float)P.bl.inv_n, pv_bl);
-    if (ext_bl) blmean = ext_bl[blockIdx.x] * ext_bl_scale;   // windowed traces of dsp_icpc_compressed (dsp_icpc.jl:353)
+    delta = s * (float)P.bl.inv_n;
+    blmean = pv_bl + delta;
+    if (ext_bl) { blmean = ext_bl[blockIdx.x] * ext_bl_scale; delta = blmean - pv_bl; }   // windowed traces of dsp_icpc_compressed (dsp_icpc.jl:353)
     raw_max = mx; raw_min = mn;
-    if (tid == 64 % NT) {   // a lane of wave 1 (wave 0 for one-wave tiles): sigma, slope, offset
-      float s2 = 0.f, sx = 0.f;
-      for (int ww = 0; ww < NW; ++ww) { s2 += S.wred[NW + ww]; sx += S.wred[2 * NW + ww]; }
-      float m_, blsigma, blslope, bloffset;
-      win_finish(s, s2, sx, P.bl, pv_bl, P.t_first, P.dt, &m_, &blsigma, &blslope, &bloffset);
-      S.outv[C_blmean] = blmean; S.outv[C_blsigma] = blsigma; S.outv[C_blslope] = blslope; S.outv[C_bloffset] = bloffset;
-      S.outv[C_e_max] = raw_max - blmean; S.outv[C_e_min] = raw_min - blmean;
-    }
   }
   const float e_max = raw_max - blmean;
+  // block-uniform scalars that are needed again much later wait in LDS, not in VGPRs
+  enum { MS_BLMEAN = 18, MS_RAWMAX, MS_RAWMIN, MS_DELTA, MS_PVTL, MS_THRI, MS_THR5, MS_EMAX };
+  if (tid == 0) { S.misc[MS_BLMEAN] = blmean; S.misc[MS_RAWMAX] = raw_max; S.misc[MS_RAWMIN] = raw_min; S.misc[MS_DELTA] = delta; S.misc[MS_EMAX] = e_max; }
   STAMP(2); DSTOP(2);
 
   // saturation (src/saturation.jl:28-65): only a trace whose extremes reach a rail can have saturated samples
   {
     int n_low = 0, n_high = 0, cons_low = 0, cons_high = 0;
     if (raw_min <= P.sat_low || raw_max >= P.sat_high) {   // block-uniform, rare
+      const float lo_ = P.sat_low, hi_ = P.sat_high;   // exact equality on the RAW samples: read again (the registers hold x')
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        n_low += (x[r].x == P.sat_low) + (x[r].y == P.sat_low) + (x[r].z == P.sat_low) + (x[r].w == P.sat_low);
-        n_high += (x[r].x == P.sat_high) + (x[r].y == P.sat_high) + (x[r].z == P.sat_high) + (x[r].w == P.sat_high);
-        *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = x[r];
+        f4 v;
+        if (P.in_u16) {
+          const uint2 q = *reinterpret_cast<const uint2*>(w16 + 4 * (tid + NT * r));
+          v = (f4){(float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16)};
+        } else {
+          v = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
+        }
+        n_low += (v.x == lo_) + (v.y == lo_) + (v.z == lo_) + (v.w == lo_);
+        n_high += (v.x == hi_) + (v.y == hi_) + (v.z == hi_) + (v.w == hi_);
+        *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = v;
       }
       n_low = wave_sum_all_i(n_low); n_high = wave_sum_all_i(n_high);
       if (lane == 0) { atomicAdd(&S.sl->imax[0], n_low); atomicAdd(&S.sl->imax[1], n_high); }   // the slots start at -1
       __syncthreads();
       for (int m = 0; m < SP; ++m) {
         const float v = S.X[tid + NT * m];
-        ballot_store(v == P.sat_low, S.bm + M_FB * NWORDS, (NT >> 5) * m + 2 * wave);
-        ballot_store(v == P.sat_high, S.bm + (M_FB + 1) * NWORDS, (NT >> 5) * m + 2 * wave);
+        ballot_store(v == lo_, S.bm + M_FB * NWORDS, (NT >> 5) * m + 2 * wave);
+        ballot_store(v == hi_, S.bm + (M_FB + 1) * NWORDS, (NT >> 5) * m + 2 * wave);
       }
       __syncthreads();
       n_low = S.sl->imax[0] + 1; n_high = S.sl->imax[1] + 1;   // the slots started at -1
@@ -434,71 +493,80 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       S.outv[C_n_sat_low_cons] = __int_as_float(cons_low); S.outv[C_n_sat_high_cons] = __int_as_float(cons_high);
     }
   }
-
-  // ------------------------------------------------------- phase 2: shift, tailstats sums, cumulative sum for the pole-zero
-  const float pv_tl = __logf(fmaxf(wv(P.tail.from) - blmean, 1e-30f));   // pivot of the log sums
-  float inc[R], tot[R];
+  __syncthreads();   // the tables of wave 0
+  // ---- y (registers) and T (-> X) of every quad; tailstats sums of log(x) on the way (src/tailstats.jl:22-72)
   {
-    const f2 bm2 = splat(blmean);
-    WAcc a = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
-    float tmin = INFINITY;   // smallest in-window sample: tailstats returns zeros if any is <= 0 (:27-33)
-    const f2 pv = splat(pv_tl);
+    const float pv_tl = __logf(fmaxf(wv(P.tail.from) - blmean, 1e-30f));   // pivot of the log sums
+    if (tid == 0) S.misc[MS_PVTL] = pv_tl;
+    // ---- tailstats sums of log(x), x = x' - delta (src/tailstats.jl:22-72), reduced at once (a loop of its own, before y takes
+    // the place of x': the two loops' temporaries do not add up)
+    {
+      float l1, l2, lx, tmin = INFINITY;
+      WAcc a = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
+      const f2 pvl = splat(pv_tl);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (row_out(cls_tail, r)) continue;
+        const int i0 = 4 * (opaque(tid) + NT * r);
+        f2 v0 = mk2(x[r].x - delta, x[r].y - delta), v1 = mk2(x[r].z - delta, x[r].w - delta);
+        const bool edge = !row_in(cls_tail, r);
+        const int lo = P.tail.from - i0, hi = P.tail.until - i0;
+        if (edge) {   // samples outside the window must not trip the sign test
+          v0.x = (lo <= 0 && hi >= 0) ? v0.x : 1.f; v0.y = (lo <= 1 && hi >= 1) ? v0.y : 1.f;
+          v1.x = (lo <= 2 && hi >= 2) ? v1.x : 1.f; v1.y = (lo <= 3 && hi >= 3) ? v1.y : 1.f;
+        }
+        tmin = vmin3(tmin, v0.x, v0.y); tmin = vmin3(tmin, v1.x, v1.y);
+        f2 d0 = mk2(__logf(fmaxf(v0.x, 1e-30f)), __logf(fmaxf(v0.y, 1e-30f))) - pvl;
+        f2 d1 = mk2(__logf(fmaxf(v1.x, 1e-30f)), __logf(fmaxf(v1.y, 1e-30f))) - pvl;
+        if (edge) {
+          d0.x = (lo <= 0 && hi >= 0) ? d0.x : 0.f; d0.y = (lo <= 1 && hi >= 1) ? d0.y : 0.f;
+          d1.x = (lo <= 2 && hi >= 2) ? d1.x : 0.f; d1.y = (lo <= 3 && hi >= 3) ? d1.y : 0.f;
+        }
+        wacc_quad(a, d0, d1, r);
+      }
+      wacc_lane<NT>(a, tid, (float)P.tail.ic, &l1, &l2, &lx);
+      LDSP_DPP_GROUP4("v_add_f32_dpp", l1, "v_add_f32_dpp", l2, "v_add_f32_dpp", lx, "v_min_f32_dpp", tmin);
+      if (lane == 63) {
+        S.wsum[(W_TAIL + 0) * NW + wave] = l1; S.wsum[(W_TAIL + 1) * NW + wave] = l2; S.wsum[(W_TAIL + 2) * NW + wave] = lx;
+        if (tmin <= 0.f) S.sl->isum[IS_TAILBAD] = 1;   // any wave may set it (same value)
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- y (registers) and T (-> X) of every quad
+    const float c = P.pz_c, cd = c * delta, hc = 0.5f * c;
+    const float n0 = (float)(4 * lane);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      x[r].xy -= bm2; x[r].zw -= bm2;
-      const f2 t = x[r].xy + x[r].zw;
-      tot[r] = t.x + t.y;
-      if (row_out(cls_tail, r)) continue;
-      f2 v0 = x[r].xy, v1 = x[r].zw;
-      const bool edge = !row_in(cls_tail, r);
-      const int lo = P.tail.from - 4 * (tid + NT * r), hi = P.tail.until - 4 * (tid + NT * r);
-      if (edge) {   // samples outside the window must not trip the sign test
-        v0.x = (lo <= 0 && hi >= 0) ? v0.x : 1.f; v0.y = (lo <= 1 && hi >= 1) ? v0.y : 1.f;
-        v1.x = (lo <= 2 && hi >= 2) ? v1.x : 1.f; v1.y = (lo <= 3 && hi >= 3) ? v1.y : 1.f;
+      const int i0 = 4 * (opaque(tid) + NT * r);
+      const float fi = (float)i0;
+      const float Hr = S.scn[4 * wave + r], Lr = S.scn[R * NW + 4 * wave + r], Br = S.scn[2 * R * NW + 4 * wave + r];   // the row's table entries
+      const float c0 = x[r].x, c1 = c0 + x[r].y, c2 = c1 + x[r].z, c3 = c2 + x[r].w;   // running sums of x' inside the quad
+      const f4 xs = (f4){x[r].x - delta, x[r].y - delta, x[r].z - delta, x[r].w - delta};   // shift_waveform
+      // y[i] = x[i] + c (C1 + cs_l) - c delta (i+1),  c C1 = B,  cs_l(e) = ex1 + c_e
+      {
+        const float ky = fmaf(c, ex1[r], Br) - cd * (fi + 1.f);
+        x[r].x = xs.x + fmaf(c, c0, ky);
+        x[r].y = xs.y + fmaf(c, c1, ky - cd);
+        x[r].z = xs.z + fmaf(c, c2, ky - 2.f * cd);
+        x[r].w = xs.w + fmaf(c, c3, ky - 3.f * cd);
       }
-      tmin = vmin3(tmin, v0.x, v0.y); tmin = vmin3(tmin, v1.x, v1.y);
-      f2 d0 = mk2(__logf(fmaxf(v0.x, 1e-30f)), __logf(fmaxf(v0.y, 1e-30f))) - pv;
-      f2 d1 = mk2(__logf(fmaxf(v1.x, 1e-30f)), __logf(fmaxf(v1.y, 1e-30f))) - pv;
-      if (edge) {
-        d0.x = (lo <= 0 && hi >= 0) ? d0.x : 0.f; d0.y = (lo <= 1 && hi >= 1) ? d0.y : 0.f;
-        d1.x = (lo <= 2 && hi >= 2) ? d1.x : 0.f; d1.y = (lo <= 3 && hi >= 3) ? d1.y : 0.f;
+      // T at the quad's first sample = hi + (lo + inner),  inner = ex1 + n B + c ex2 - delta (i + c i (i+1) / 2)  (n = 4 lane,
+      // i = i0); at its other samples inner grows by the y in front of them: one rounding at the magnitude of T
+      {
+        const float in0 = fmaf(-delta, fi * fmaf(hc, fi + 1.f, 1.f), fmaf(c, ex2[r], fmaf(n0, Br, ex1[r])));
+        const float in1 = in0 + x[r].x, in2 = in1 + x[r].y, in3 = in2 + x[r].z;
+        const float H = Hr, Lo = Lr;
+        *reinterpret_cast<f4*>(&S.X[i0]) = (f4){H + (Lo + in0), H + (Lo + in1), H + (Lo + in2), H + (Lo + in3)};
       }
-      wacc_quad(a, d0, d1, r);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    float s1, s2, sx;
-    wacc_lane<NT>(a, tid, (float)P.tail.ic, &s1, &s2, &sx);
-#pragma unroll
-    for (int r = 0; r < R; ++r) inc[r] = tot[r];
-    LDSP_DPP_GROUP8("v_add_f32_dpp", inc[0], "v_add_f32_dpp", inc[1], "v_add_f32_dpp", inc[2], "v_add_f32_dpp", inc[3], "v_add_f32_dpp", s1, "v_add_f32_dpp", s2, "v_add_f32_dpp", sx, "v_min_f32_dpp", tmin);
-    if (lane == 63) {
-      *reinterpret_cast<f4*>(&S.part[4 * wave]) = (f4){inc[0], inc[1], inc[2], inc[3]};   // [wave][r]
-      S.wsum[(W_TAIL + 0) * NW + wave] = s1; S.wsum[(W_TAIL + 1) * NW + wave] = s2; S.wsum[(W_TAIL + 2) * NW + wave] = sx;
-      if (tmin <= 0.f) S.sl->isum[IS_TAILBAD] = 1;   // any wave may set it (same value)
-    }
+    if (tid == 0) S.X[Lp] = S.misc[16] + (S.misc[17] - delta * ((float)L * fmaf(hc, (float)(L + 1), 1.f)));   // T[L]
   }
-  STAMP(3); DSTOP(3);
-  __syncthreads();
-  pz_offsets_scan<NW>(S.part, S.scn, P.pz_c64, wave, lane);
-  if (tid == (128 % NT)) {   // a lane of wave 2: tailstats -> (mean, sigma, tau)
-    float tail_mean = 0.f, tail_sigma = 0.f, tail_tau = 0.f;
-    if (S.sl->isum[IS_TAILBAD] == 0) {
-      float s1 = 0.f, s2 = 0.f, sx = 0.f, sl, of;
-      for (int ww = 0; ww < NW; ++ww) { s1 += S.wsum[(W_TAIL + 0) * NW + ww]; s2 += S.wsum[(W_TAIL + 1) * NW + ww]; sx += S.wsum[(W_TAIL + 2) * NW + ww]; }
-      win_finish(s1, s2, sx, P.tail, pv_tl, P.t_first, P.dt, &tail_mean, &tail_sigma, &sl, &of);
-      tail_tau = -__builtin_amdgcn_rcpf(sl);
-    }
-    S.outv[C_tail_tau] = tail_tau; S.outv[C_tail_mean] = tail_mean; S.outv[C_tail_sigma] = tail_sigma;
-  }
-  // InvCRFilter: y = x + c*cumsum(x)  (dsp_icpc.jl:119-120); x becomes y
-  __syncthreads();
-  pz_apply<NW>(x, inc, tot, S.scn, P.pz_c, wave);
   auto& y = x;
-  STAMP(4); DSTOP(4);
-
   // get_threshold at 10 / 50 / 80 / 90 / 99 % of the pre-PZ maximum (dsp_icpc.jl:132-136): first quad of this wave reaching
-  // each threshold (ballots on the quad maxima); confirmed later, when y is in LDS.
-  const float thr_tx[5] = {e_max * 0.1f, e_max * 0.5f, e_max * 0.8f, e_max * 0.9f, e_max * 0.99f};
+  // each threshold (ballots on the quad maxima); confirmed when y is in LDS.
   if (e_max > 0.f) {
+    const float thr_tx[5] = {e_max * 0.1f, e_max * 0.5f, e_max * 0.8f, e_max * 0.9f, e_max * 0.99f};
     int qfirst[5] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
     bool all_found = false;   // wave-uniform
 #pragma unroll
@@ -520,8 +588,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       if (qq != 0x7fffffff) atomicMin(&S.sl->imin[IM_TX0 + lane], qq);
     }
   }
-
-  // ------------------------------------------------------------------------------------ phase 3: T = prefix sum of y -> X
+  if (tid == 0) S.misc[15] = y[0].x;   // y[0] (the CUSP / ZAC stage: Dp = y - y[0] + eps T)
   {   // pivot of signalstats(pole-zero corrected tail): the window's first sample, from its owner's registers
     const int tq = P.tail.from >> 2, tr = tq / NT, te = P.tail.from & 3;   // (block-uniform)
     if (tid == tq - NT * tr) {
@@ -529,32 +596,31 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       S.misc[14] = (te == 0) ? v.x : (te == 1) ? v.y : (te == 2) ? v.z : v.w;
     }
   }
-  {
-    float tin[R], p0[R];   // p0: sum of the wave-row's samples before this lane's quad
+  // the first NH quads of every wave-row: halo of the previous wave-row's last lanes (sweep A's short leg, Savitzky-Golay)
+  constexpr int NH = (M + 3 - 4 + 3) / 4;
+  float* hyl = S.hy + 4 * NH * (R * NW + 1);
+  if (lane < NH) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) { const f2 t = y[r].xy + y[r].zw; tot[r] = t.x + t.y; tin[r] = tot[r]; }
-    LDSP_DPP_GROUP4("v_add_f32_dpp", tin[0], "v_add_f32_dpp", tin[1], "v_add_f32_dpp", tin[2], "v_add_f32_dpp", tin[3]);
-#pragma unroll
-    for (int r = 0; r < R; ++r) p0[r] = tin[r] - tot[r];
-    float* pb = S.part + R * NW;   // second buffer
-    if (lane == 63) *reinterpret_cast<f4*>(&pb[4 * wave]) = (f4){tin[0], tin[1], tin[2], tin[3]};
-    if (lane == 0) {   // the first two samples of every wave-row: halo of the previous wave-row's last lane (sweep A)
-#pragma unroll
-      for (int r = 0; r < R; ++r) *reinterpret_cast<f2*>(&S.hy[2 * (r * NW + wave)]) = y[r].xy;
-    }
-    __syncthreads();
-    t_offsets_scan<NW>(pb, S.scn + R * NW, &S.X[Lp], wave, lane);   // wave 0; T[L] -> X[Lp]
-    __syncthreads();
-    const float* hilo = S.scn + R * NW;
-    const f4 h = *reinterpret_cast<const f4*>(&hilo[4 * wave]), l = *reinterpret_cast<const f4*>(&hilo[R * NW + 4 * wave]);
-    const float hw[R] = {h.x, h.y, h.z, h.w}, lw[R] = {l.x, l.y, l.z, l.w};
-#pragma unroll
-    for (int r = 0; r < R; ++r) *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = t_quad(y[r], p0[r], hw[r], lw[r]);
+    for (int r = 0; r < R; ++r) *reinterpret_cast<f4*>(&S.hy[4 * (NH * (r * NW + wave) + lane)]) = y[r];
   }
-  __syncthreads();
-  STAMP(5); DSTOP(5);
+  if (lane == 63) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) hyl[r * NW + wave + 1] = y[r].w;
+  }
+  if (tid < 4 * NH) S.hy[4 * NH * R * NW + tid] = 0.f;
+  STAMP(3); DSTOP(3);
+  __syncthreads();   // X = T; halo table, threshold candidates, pivot
+  // quad j + 1, j + 2, .. of the thread's row (the next lanes' registers; for the last lanes the next wave-row's first quads)
+  auto halo_next = [&](f4 q, int r, int level) {
+    f4 h = (f4){wave_shl1(q.x), wave_shl1(q.y), wave_shl1(q.z), wave_shl1(q.w)};
+    const f4 t = *reinterpret_cast<const f4*>(&S.hy[4 * (NH * (r * NW + wave + 1) + level)]);
+    if (lane == 63) h = t;
+    return h;
+  };
 
-  // ------------------------------------------------------------------------------------ phase 4: sweeps over T
+  // ================================================================== round 2: sweeps over T, Savitzky-Golay from registers
+  float mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY, mn0 = INFINITY, mn2 = INFINITY;
+  float bo_v = -INFINITY; int bo_i = 0x7fffffff;
   {
     // ---- sweep A, S4 view: the two threshold masks of the t0 trapezoid (get_t0, dsp_routines.jl:9-25; inverted: dsp_icpc.jl:207).
     // o'[k] = (T[k+flen] - T[k+n1+g]) * (inv2/inv1) - (first leg's sum).  A first leg of <= 3 samples (get_t0's 40 ns) is summed
@@ -567,21 +633,23 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       const int s_b = t0.n1 + t0.g, s_c = t0.flen;
       const bool short1 = t0.n1 <= 3;
       uint32_t wp[R], wn[R];
+      // (get_t0's own geometry — second leg at a multiple of four samples, end at an odd one — has a copy of the loop without
+      // alignment tests; other geometries decide per quad read)
+      auto rows = [&](auto fast_tag) {
+      constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         wp[r] = 0u; wn[r] = 0u;
         if (4 * NT * r >= nout) continue;   // row beyond the output range
-        const int i0 = 4 * (tid + NT * r);
+        const int i0 = 4 * (opaque(tid) + NT * r);
         const int ic = min(i0, (nout - 1) & ~3);   // quads beyond the output range read the last one's addresses (masked below)
-        const f4 tb4 = rdq(S.X, ic + s_b, s_b & 3), tc4 = rdq(S.X, ic + s_c, s_c & 3);
+        const f4 tb4 = FAST ? rdq_t<0>(S.X, ic + s_b) : rdq(S.X, ic + s_b, s_b & 3), tc4 = FAST ? rdq_t<1>(S.X, ic + s_c) : rdq(S.X, ic + s_c, s_c & 3);
         f4 sl;
         if (short1) {
-          float h0 = wave_shl1(y[r].x), h1 = wave_shl1(y[r].y);   // the next lane's first two samples
-          const f2 hn = *reinterpret_cast<const f2*>(&S.hy[2 * (r * NW + wave + 1)]);   // ... of the next wave-row, for lane 63
-          h0 = (lane == 63) ? hn.x : h0; h1 = (lane == 63) ? hn.y : h1;
+          const f4 hn = halo_next(y[r], r, 0);
           sl = y[r];
-          if (t0.n1 >= 2) sl += (f4){y[r].y, y[r].z, y[r].w, h0};
-          if (t0.n1 >= 3) sl += (f4){y[r].z, y[r].w, h0, h1};
+          if (t0.n1 >= 2) sl += (f4){y[r].y, y[r].z, y[r].w, hn.x};
+          if (t0.n1 >= 3) sl += (f4){y[r].z, y[r].w, hn.x, hn.y};
         } else {
           sl = rdq(S.X, ic + t0.n1, t0.n1 & 3) - *reinterpret_cast<const f4*>(&S.X[ic]);
         }
@@ -595,6 +663,9 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         wp[r] = s4_pack_word(nib_ge(o, thr0), lane);
         wn[r] = s4_pack_word(nib_le(o, mthr0), lane);   // -trap >= thr
       }
+      };
+      if ((s_b & 3) == 0 && (s_c & 1) == 1) rows(std::true_type{});
+      else rows(std::false_type{});
       static_assert(M_T0INV == M_T0 + 1, "mask order");
       if ((lane & 7) == 7) {   // word of (row r, wave, lane group): samples 4 (64 wave + 8 (lane >> 3) + NT r) ..
         uint32_t* bw = S.bm + M_T0 * NWORDS + 8 * wave + (lane >> 3);
@@ -602,99 +673,134 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         for (int r = 0; r < R; ++r) { bw[(NT / 8) * r] = wp[r]; bw[NWORDS + (NT / 8) * r] = wn[r]; }
       }
     }
-    STAMP(6); DSTOP(6);
+    STAMP(4); DSTOP(4);
     // ---- sweep B, LS view: extrema of the three fixed trapezoids, arg-max of the optimised one (dsp_icpc.jl:147-164, 202-204);
     // two rows per step (one ds_read2st64_b32 per shift), packed arithmetic
     const float* tb = &S.X[tid];
     auto rd2 = [&](const float* p, int m) { return mk2(p[NT * m], p[NT * (m + 1)]); };
-    float mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY, mn0 = INFINITY, mn2 = INFINITY;
-    float bo_v = -INFINITY; int bo_i = 0x7fffffff;
+    // (two trapezoids per pass over the rows — seven address registers and two trapezoids' reads in flight at a time — and T[k]
+    // read once more: the register budget of three workgroups per CU)
     {
-      const TrapDev f0 = P.fixed[0], f1 = P.fixed[1], f2_ = P.fixed[2], fo = P.opt;
+      const TrapDev f0 = P.fixed[0], f1 = P.fixed[1];
       const float *f0a = tb + f0.n1, *f0b = tb + f0.n1 + f0.g, *f0c = tb + f0.flen;
       const float *f1a = tb + f1.n1, *f1b = tb + f1.n1 + f1.g, *f1c = tb + f1.flen;
-      const float *f2a = tb + f2_.n1, *f2b = tb + f2_.n1 + f2_.g, *f2c = tb + f2_.flen;
-      const float *foa = tb + fo.n1, *fob = tb + fo.n1 + fo.g, *foc = tb + fo.flen;
-      const f2 rr0 = splat(f0.rr), rr1 = splat(f1.rr), rr2 = splat(f2_.rr), rro = splat(fo.rr);
-      const int n0 = L - f0.flen + 1, n1 = L - f1.flen + 1, n2 = L - f2_.flen + 1, no = L - fo.flen + 1;
-      const int nall = min(min(n0, n1), min(n2, no));
+      const f2 rr0 = splat(f0.rr), rr1 = splat(f1.rr);
+      const int n0 = L - f0.flen + 1, n1 = L - f1.flen + 1;
 #pragma unroll
       for (int m = 0; m < SP; m += 2) {
-        if (NT * m >= max(max(n0, n1), max(n2, no))) continue;   // pair beyond every output range
+        if (NT * m >= max(n0, n1)) continue;   // pair beyond both output ranges
         const f2 Tk = rd2(tb, m);
         const f2 a0 = rd2(f0a, m), b0 = rd2(f0b, m), c0_ = rd2(f0c, m);
         const f2 a1 = rd2(f1a, m), b1 = rd2(f1b, m), c1_ = rd2(f1c, m);
-        const f2 a2 = rd2(f2a, m), b2 = rd2(f2b, m), c2_ = rd2(f2c, m);
-        const f2 ao = rd2(foa, m), bo = rd2(fob, m), co = rd2(foc, m);
-        f2 o0 = fma2(c0_ - b0, rr0, Tk - a0), o1 = fma2(c1_ - b1, rr1, Tk - a1), o2 = fma2(c2_ - b2, rr2, Tk - a2), oo = fma2(co - bo, rro, Tk - ao);
-        if (NT * (m + 2) <= nall) {   // pair wholly inside every output range (most pairs)
+        const f2 o0 = fma2(c0_ - b0, rr0, Tk - a0), o1 = fma2(c1_ - b1, rr1, Tk - a1);
+        if (NT * (m + 2) <= min(n0, n1)) {   // pair wholly inside both output ranges (most pairs)
           mx0 = vmax3(mx0, o0.x, o0.y); mn0 = vmin3(mn0, o0.x, o0.y);
           mx1 = vmax3(mx1, o1.x, o1.y);
-          mx2 = vmax3(mx2, o2.x, o2.y); mn2 = vmin3(mn2, o2.x, o2.y);
         } else {
-          const int k0 = tid + NT * m, k1 = k0 + NT;
+          const int k0 = opaque(tid) + NT * m, k1 = k0 + NT;
           mx0 = vmax3(mx0, k0 < n0 ? o0.x : -INFINITY, k1 < n0 ? o0.y : -INFINITY);
           mn0 = vmin3(mn0, k0 < n0 ? o0.x : INFINITY, k1 < n0 ? o0.y : INFINITY);
           mx1 = vmax3(mx1, k0 < n1 ? o1.x : -INFINITY, k1 < n1 ? o1.y : -INFINITY);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mx0 *= f0.inv1; mn0 *= f0.inv1; mx1 *= f1.inv1;
+    }
+    {
+      const TrapDev f2_ = P.fixed[2], fo = P.opt;
+      const float *f2a = tb + f2_.n1, *f2b = tb + f2_.n1 + f2_.g, *f2c = tb + f2_.flen;
+      const float *foa = tb + fo.n1, *fob = tb + fo.n1 + fo.g, *foc = tb + fo.flen;
+      const f2 rr2 = splat(f2_.rr), rro = splat(fo.rr);
+      const int n2 = L - f2_.flen + 1, no = L - fo.flen + 1;
+#pragma unroll
+      for (int m = 0; m < SP; m += 2) {
+        if (NT * m >= max(n2, no)) continue;
+        const f2 Tk = rd2(tb, m);
+        const f2 a2 = rd2(f2a, m), b2 = rd2(f2b, m), c2_ = rd2(f2c, m);
+        const f2 ao = rd2(foa, m), bo = rd2(fob, m), co = rd2(foc, m);
+        const f2 o2 = fma2(c2_ - b2, rr2, Tk - a2);
+        f2 oo = fma2(co - bo, rro, Tk - ao);
+        if (NT * (m + 2) <= min(n2, no)) {
+          mx2 = vmax3(mx2, o2.x, o2.y); mn2 = vmin3(mn2, o2.x, o2.y);
+        } else {
+          const int k0 = opaque(tid) + NT * m, k1 = k0 + NT;
           mx2 = vmax3(mx2, k0 < n2 ? o2.x : -INFINITY, k1 < n2 ? o2.y : -INFINITY);
           mn2 = vmin3(mn2, k0 < n2 ? o2.x : INFINITY, k1 < n2 ? o2.y : INFINITY);
           oo.x = k0 < no ? oo.x : -INFINITY; oo.y = k1 < no ? oo.y : -INFINITY;
         }
-        if (oo.x > bo_v) { bo_v = oo.x; bo_i = tid + NT * m; }
-        if (oo.y > bo_v) { bo_v = oo.y; bo_i = tid + NT * (m + 1); }
+        if (oo.x > bo_v) { bo_v = oo.x; bo_i = opaque(tid) + NT * m; }
+        if (oo.y > bo_v) { bo_v = oo.y; bo_i = opaque(tid) + NT * (m + 1); }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      mx0 *= f0.inv1; mn0 *= f0.inv1; mx1 *= f1.inv1; mx2 *= f2_.inv1; mn2 *= f2_.inv1; bo_v *= fo.inv1;
+      mx2 *= f2_.inv1; mn2 *= f2_.inv1; bo_v *= fo.inv1;
     }
-    STAMP(7); DSTOP(7);
-    // signalstats of the pole-zero corrected tail (dsp_icpc.jl:122) from the registers, pivot = its first sample
-    float t1, t2, tx;
-    {
-      WAcc a = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
-      const f2 pvz = splat(S.misc[14]);
+  }
+  STAMP(5); DSTOP(5);
+  // ---- signalstats of the pole-zero corrected tail (dsp_icpc.jl:122) from the registers, pivot = its first sample
+  float t1, t2, tx;
+  {
+    WAcc a = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
+    const f2 pvz = splat(S.misc[14]);
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (row_out(cls_tail, r)) continue;
-        const int i0 = 4 * (tid + NT * r);
-        f2 d0 = y[r].xy - pvz, d1 = y[r].zw - pvz;
-        if (!row_in(cls_tail, r)) {
-          const int lo = P.tail.from - i0, hi = P.tail.until - i0;
-          d0.x = (lo <= 0 && hi >= 0) ? d0.x : 0.f; d0.y = (lo <= 1 && hi >= 1) ? d0.y : 0.f;
-          d1.x = (lo <= 2 && hi >= 2) ? d1.x : 0.f; d1.y = (lo <= 3 && hi >= 3) ? d1.y : 0.f;
-        }
-        wacc_quad(a, d0, d1, r);
+    for (int r = 0; r < R; ++r) {
+      if (row_out(cls_tail, r)) continue;
+      const int i0 = 4 * (opaque(tid) + NT * r);
+      f2 d0 = y[r].xy - pvz, d1 = y[r].zw - pvz;
+      if (!row_in(cls_tail, r)) {
+        const int lo = P.tail.from - i0, hi = P.tail.until - i0;
+        d0.x = (lo <= 0 && hi >= 0) ? d0.x : 0.f; d0.y = (lo <= 1 && hi >= 1) ? d0.y : 0.f;
+        d1.x = (lo <= 2 && hi >= 2) ? d1.x : 0.f; d1.y = (lo <= 3 && hi >= 3) ? d1.y : 0.f;
       }
-      wacc_lane<NT>(a, tid, (float)P.tail.ic, &t1, &t2, &tx);
+      wacc_quad(a, d0, d1, r);
     }
+    wacc_lane<NT>(a, tid, (float)P.tail.ic, &t1, &t2, &tx);
+  }
+  // ---- reductions of the sweeps and of the tail sums (before the SG pass: fourteen registers less across it)
+  {
     LDSP_DPP_GROUP8("v_max_f32_dpp", mx0, "v_max_f32_dpp", mx1, "v_max_f32_dpp", mx2, "v_min_f32_dpp", mn0, "v_min_f32_dpp", mn2, "v_add_f32_dpp", t1, "v_add_f32_dpp", t2, "v_add_f32_dpp", tx);
     wave_argmax(bo_v, bo_i);
-    const unsigned long long bo = pack_vi(bo_v, bo_i);
     if (lane == 63) {
-      S.wsum[(W_PZ + 0) * NW + wave] = t1; S.wsum[(W_PZ + 1) * NW + wave] = t2; S.wsum[(W_PZ + 2) * NW + wave] = tx;
       atomicMax(&S.sl->fmx[FX_F0], ford(mx0));
       atomicMax(&S.sl->fmx[FX_F1], ford(mx1));
       atomicMax(&S.sl->fmx[FX_F2], ford(mx2));
       atomicMax(&S.sl->fmx[FX_F0I], ford(-mn0));   // max(trap(-y)) = -min(trap(y))
       atomicMax(&S.sl->fmx[FX_F2I], ford(-mn2));
-      atomicMax(&S.sl->vi[VI_OPT], bo);
+      atomicMax(&S.sl->vi[VI_OPT], pack_vi(bo_v, bo_i));
+      S.wsum[(W_PZ + 0) * NW + wave] = t1; S.wsum[(W_PZ + 1) * NW + wave] = t2; S.wsum[(W_PZ + 2) * NW + wave] = tx;
     }
   }
-  __syncthreads();   // every read of T is done
-  STAMP(8); DSTOP(8);
-
-  // ------------------------------------------------------------------ phase 5: y -> X; Savitzky-Golay derivatives, current maxima
-#pragma unroll
-  for (int r = 0; r < R; ++r) *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = y[r];
-  if (tid < 64) S.X[Lp + tid] = 0.f;
-  __syncthreads();   // X = y visible to every wave
-  STAMP(9); DSTOP(9);
+  // ---- Savitzky-Golay derivatives, current maxima (dsp_icpc.jl:181-186): g[k] = sum_i c[i] y[k+i] (valid mode, trailing time
+  // axis).  The four outputs of a quad from the M + 3 samples w[0 .. M+2] = the quad and its halo (the next lanes' registers by
+  // DPP), one multiply-add per tap and output.  This pass takes the statistics (maximum, baseline sums, current maxima); the
+  // masks of the main filter's output need thresholds that follow from them: its four outputs per quad are computed again after
+  // the exchange (28 multiply-adds per quad against sixteen registers across the barrier).
   const int ng = L - P.sg_npts[0] + 1;
-  f4 g[R];   // SG(sg_npts[0]) output of the thread's quads (valid mode, trailing time axis); -inf beyond the output axis
+  auto sg_window = [&](int r, float (&wv_)[4 + 4 * NH]) {
+    wv_[0] = y[r].x; wv_[1] = y[r].y; wv_[2] = y[r].z; wv_[3] = y[r].w;
+    f4 h = y[r];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      h = halo_next(h, r, j);
+      wv_[4 + 4 * j] = h.x; wv_[5 + 4 * j] = h.y; wv_[6 + 4 * j] = h.z; wv_[7 + 4 * j] = h.w;
+    }
+  };
+  auto sg_main = [&](int r, const float (&wv_)[4 + 4 * NH], float (&go)[4]) {   // -inf beyond the output axis
+    const int i0 = 4 * (opaque(tid) + NT * r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) go[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const float c = P.sg_c[0][i];   // zero beyond the filter's own taps (the host zero-fills the block)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) go[e] = fmaf(c, wv_[e + i], go[e]);
+    }
+    if (wrow(r) + 255 >= ng) {   // only the wave-row holding the end of the output axis
+#pragma unroll
+      for (int e = 0; e < 4; ++e) go[e] = (i0 + e < ng) ? go[e] : -INFINITY;
+    }
+  };
   {
-    // g[k] = sum_i c[i] y[k+i]: the four outputs of a quad from the M + 3 samples w[0 .. M+2] = the quad and its halo, one
-    // multiply-add per tap and output with the tap in a register (packed arithmetic on (even, odd) pairs needed every odd-aligned
-    // pair assembled by two moves and twice the registers for the taps: no fewer VALU cycles, 19 more VGPRs)
-    float gmax = -INFINITY;
-    float g_s1 = 0.f, g_s2 = 0.f;   // sums of the SG output over the baseline window (pivot 0: a derivative has no level)
+    float gmax = -INFINITY, g_s1 = 0.f, g_s2 = 0.f;   // maximum; sums over the baseline window (pivot 0: a derivative has no level)
     float bv[4]; int bi[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) { bv[f] = -INFINITY; bi[f] = 0x7fffffff; }
@@ -707,32 +813,13 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       bv[f] = gt ? gw : bv[f];
       bi[f] = gt ? k : bi[f];
     };
-    float c0[M];
-#pragma unroll
-    for (int i = 0; i < M; ++i) c0[i] = P.sg_c[0][i];   // zero beyond the filter's own taps (the host zero-fills the block)
-    constexpr int NH = (M + 3 - 4 + 3) / 4;   // halo quads
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int i0 = 4 * (tid + NT * r);
-      float wv_[4 + 4 * NH];
-      wv_[0] = y[r].x; wv_[1] = y[r].y; wv_[2] = y[r].z; wv_[3] = y[r].w;
-#pragma unroll
-      for (int j = 0; j < NH; ++j) {   // halo (runs past the trace into the zero margin: only masked outputs see that)
-        const f4 h = *reinterpret_cast<const f4*>(&S.X[i0 + 4 + 4 * j]);
-        wv_[4 + 4 * j] = h.x; wv_[5 + 4 * j] = h.y; wv_[6 + 4 * j] = h.z; wv_[7 + 4 * j] = h.w;
-      }
-      float go[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < M; ++i) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) go[e] = fmaf(c0[i], wv_[e + i], go[e]);
-      }
-      if (wrow(r) + 255 >= ng) {   // only the wave-row holding the end of the output axis
-#pragma unroll
-        for (int e = 0; e < 4; ++e) go[e] = (i0 + e < ng) ? go[e] : -INFINITY;
-      }
+      const int i0 = 4 * (opaque(tid) + NT * r);
+      float wv_[4 + 4 * NH], go[4];
+      sg_window(r, wv_);
+      sg_main(r, wv_, go);
       gmax = vmax3(vmax3(gmax, go[0], go[1]), go[2], go[3]);
-      g[r] = (f4){go[0], go[1], go[2], go[3]};
       if (!row_out(cls_sgbl, r)) {   // sgbl.until <= ng-1: -inf never enters
         float dd[4] = {go[0], go[1], go[2], go[3]};
         if (!row_in(cls_sgbl, r)) {
@@ -748,88 +835,94 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         for (int e = 0; e < 4; ++e) track(0, i0 + e, go[e]);
       }
       if (!row_out(cls_curx, r)) {   // SG(60 ns), SG(100 ns), plain derivative: only rows that touch the current window
-        float g1[4] = {0.f, 0.f, 0.f, 0.f}, g2[4] = {0.f, 0.f, 0.f, 0.f};
+        // (one filter at a time, its four outputs tracked before the next one's are computed)
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-          const float c = P.sg_c[1][i];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) g1[e] = fmaf(c, wv_[e + i], g1[e]);
-        }
-        if (!P.sg_same_02) {
+        for (int f = 1; f < 3; ++f) {
+          if (f == 2 && P.sg_same_02) continue;
+          float gf[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int i = 0; i < M; ++i) {
-            const float c = P.sg_c[2][i];
+            const float c = P.sg_c[f][i];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g2[e] = fmaf(c, wv_[e + i], g2[e]);
+            for (int e = 0; e < 4; ++e) gf[e] = fmaf(c, wv_[e + i], gf[e]);
           }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) track(f, i0 + e, gf[e]);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        const float ypv = (i0 > 0) ? S.X[i0 - 1] : 0.f;
+        // y[k] - y[k-1]: the sample before the quad is the previous lane's last one (lane 0: the previous wave-row's, from the table)
+        float ypv;   // (as an asm statement: through __builtin_amdgcn_update_dpp hipcc 7.2 shifted y[r].x here, not y[r].w)
+        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(ypv) : "v"(y[r].w));
+        if (lane == 0) ypv = (i0 > 0) ? hyl[r * NW + wave] : 0.f;
         float g3[4] = {y[r].x - ypv, y[r].y - y[r].x, y[r].z - y[r].y, y[r].w - y[r].z};   // y[k] - y[k-1]
         if (i0 == 0) g3[0] = y[r].y - y[r].x;                                                // y[max(i,1)] - y[max(i-1,0)] at i = 0
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          track(1, i0 + e, g1[e]);
-          if (!P.sg_same_02) track(2, i0 + e, g2[e]);
-          track(3, i0 + e, g3[e]);
-        }
+        for (int e = 0; e < 4; ++e) track(3, i0 + e, g3[e]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    STAMP(10); DSTOP(10);
-    LDSP_DPP_GROUP3("v_add_f32_dpp", g_s1, "v_add_f32_dpp", g_s2, "v_max_f32_dpp", gmax);
-    if (lane == 63) {
-      S.wsum[(W_SGB + 0) * NW + wave] = g_s1; S.wsum[(W_SGB + 1) * NW + wave] = g_s2;
-      atomicMax(&S.sl->fmx[FX_G], ford(gmax));
-    }
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      if (f == 2 && P.sg_same_02) continue;
-      if (__ballot(bi[f] != 0x7fffffff) != 0ull) {
-        wave_argmax(bv[f], bi[f]);
-        if (lane == 63) atomicMax(&S.sl->vi[VI_CUR0 + f], pack_vi(bv[f], bi[f]));
-      }
-    }
-  }
-  // Confirmation of the five threshold candidates (see icpc_lean.hip): imin[q] = first QUAD with a sample at or above
-  // threshold q; lane q of every wave finds the sample, checks that it is not sample 0 and that the next tx_mintot - 1 samples
-  // stay at or above the threshold.  A trace that fails runs the general scan (bit-masks of y by ballot, run scan on the words).
-  // (The candidates were posted before the barriers of phase 3.)
-  int p_tx = 0x7fffffff;   // lane q < 5: first confirmed sample of threshold q
+  STAMP(6); DSTOP(6);
+  // ---- the SG pass's own reductions
+  LDSP_DPP_GROUP3("v_max_f32_dpp", gmax, "v_add_f32_dpp", g_s1, "v_add_f32_dpp", g_s2);
   {
-    const int q = min(lane, 4);
-    const float thrq = e_max * ((q == 0) ? 0.1f : (q == 1) ? 0.5f : (q == 2) ? 0.8f : (q == 3) ? 0.9f : 0.99f);   // = thr_tx[q]
-    const int qd = S.sl->imin[IM_TX0 + q];
-    bool ok = e_max > 0.f;
-    if (ok && qd != 0x7fffffff) {
-      const f4 v = *reinterpret_cast<const f4*>(&S.X[4 * qd]);
-      const int e = (v.x >= thrq) ? 0 : (v.y >= thrq) ? 1 : (v.z >= thrq) ? 2 : 3;
-      p_tx = 4 * qd + e;
-      ok = p_tx >= 1 && p_tx + P.tx_mintot <= L;
-      for (int j = 1; ok && j < P.tx_mintot; ++j) ok = S.X[p_tx + j] >= thrq;
-    }
-    if (__ballot(lane < 5 && !ok) != 0ull) {   // block-uniform
-      __syncthreads();
-      if (tid < 5) S.sl->imin[IM_TX0 + tid] = 0x7fffffff;
-      for (int m = 0; m < SP; ++m) {
-        const float yv = S.X[tid + NT * m];
-#pragma unroll
-        for (int qq = 0; qq < 5; ++qq) {
-          const unsigned long long b = __ballot(yv >= e_max * ((qq == 0) ? 0.1f : (qq == 1) ? 0.5f : (qq == 2) ? 0.8f : (qq == 3) ? 0.9f : 0.99f));
-          if (lane == 0) *reinterpret_cast<unsigned long long*>(&S.bm[(M_FB + qq) * NWORDS + (NT >> 5) * m + 2 * wave]) = b;
-        }
-      }
-      __syncthreads();
-      for (int j = tid; j < 5 * NWORDS; j += NT) {
-        const int qq = j / NWORDS, wd = j % NWORDS;
-        int c, f;
-        intersect_word(S.bm + (M_FB + qq) * NWORDS, wd, NWORDS, P.tx_mintot, &c, &f);
-        if (c) atomicMin(&S.sl->imin[IM_TX0 + qq], f);
-      }
-      __syncthreads();
-      p_tx = S.sl->imin[IM_TX0 + q];
+    float v0 = bv[0], v1 = bv[1], v2 = bv[2], v3 = bv[3];
+    LDSP_DPP_GROUP4("v_max_f32_dpp", v0, "v_max_f32_dpp", v1, "v_max_f32_dpp", v2, "v_max_f32_dpp", v3);
+    uint32_t k0 = (bv[0] == readlane_f(v0, 63)) ? (uint32_t)bi[0] : 0x7fffffffu, k1 = (bv[1] == readlane_f(v1, 63)) ? (uint32_t)bi[1] : 0x7fffffffu,
+             k2 = (bv[2] == readlane_f(v2, 63)) ? (uint32_t)bi[2] : 0x7fffffffu, k3 = (bv[3] == readlane_f(v3, 63)) ? (uint32_t)bi[3] : 0x7fffffffu;
+    LDSP_DPP_GROUP4("v_min_u32_dpp", k0, "v_min_u32_dpp", k1, "v_min_u32_dpp", k2, "v_min_u32_dpp", k3);
+    if (lane == 63) {
+      atomicMax(&S.sl->fmx[FX_G], ford(gmax));
+      if (k0 != 0x7fffffffu) atomicMax(&S.sl->vi[VI_CUR0], pack_vi(v0, (int)k0));
+      if (k1 != 0x7fffffffu) atomicMax(&S.sl->vi[VI_CUR1], pack_vi(v1, (int)k1));
+      if (k2 != 0x7fffffffu) atomicMax(&S.sl->vi[VI_CUR2], pack_vi(v2, (int)k2));
+      if (k3 != 0x7fffffffu) atomicMax(&S.sl->vi[VI_CUR3], pack_vi(v3, (int)k3));
+      S.wsum[(W_SGB + 0) * NW + wave] = g_s1; S.wsum[(W_SGB + 1) * NW + wave] = g_s2;
     }
   }
-  __syncthreads();
-  STAMP(11); DSTOP(11);
+  }
+  STAMP(7); DSTOP(7);
+  __syncthreads();   // every read of T is done; the round's results are posted
+  STAMP(8); DSTOP(8);
+
+  // ================================================================== round 3: y -> X; the masks of the SG output from registers
+#pragma unroll
+  for (int r = 0; r < R; ++r) *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = y[r];
+  if (tid < 64) S.X[Lp + tid] = 0.f;
+  // in-trace pile-up threshold (dsp_routines.jl:75-77) and t50_current threshold (dsp_icpc.jl:192) (g = -inf beyond the output
+  // axis: bit 0)
+  {
+    float thr_intr, thr_sg50;
+    const float s1 = fold_partials<NW>(S.wsum + (W_SGB + 0) * NW, 0.f, [](float a, float b) { return a + b; });
+    const float s2 = fold_partials<NW>(S.wsum + (W_SGB + 1) * NW, 0.f, [](float a, float b) { return a + b; });
+    const float m_ = s1 * (float)P.sgbl.inv_n;
+    const float var_ = fmaxf(fmaf(s2, (float)P.sgbl.inv_n, -m_ * m_), 0.f);
+    thr_intr = __builtin_amdgcn_sqrtf(var_) * P.intrace_nsigma;
+    if (thr_intr == 0.f) thr_intr = 1.f;
+    thr_sg50 = ford_inv(S.sl->fmx[FX_G]) * 0.5f;
+    if (tid == 0) { S.misc[MS_THRI] = thr_intr; S.misc[MS_THR5] = thr_sg50; }
+    uint32_t wi[R], w5[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float wv_[4 + 4 * NH], go[4];
+      sg_window(r, wv_);
+      sg_main(r, wv_, go);
+      const f4 gq = (f4){go[0], go[1], go[2], go[3]};
+      wi[r] = s4_pack_word(nib_ge(gq, thr_intr), lane); w5[r] = s4_pack_word(nib_ge(gq, thr_sg50), lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if ((lane & 7) == 7) {
+      uint32_t* bi_ = S.bm + M_INTR * NWORDS + 8 * wave + (lane >> 3);
+      uint32_t* b5_ = S.bm + M_SG50 * NWORDS + 8 * wave + (lane >> 3);
+#pragma unroll
+      for (int r = 0; r < R; ++r) { bi_[(NT / 8) * r] = wi[r]; b5_[(NT / 8) * r] = w5[r]; }
+    }
+  }
+  STAMP(9); DSTOP(9);
+  __syncthreads();   // X = y and the four masks are complete
+  STAMP(10); DSTOP(10);
+
+  // ================================================================== round 4: run scans on the masks, threshold confirmation
+  const float e_maxl = S.misc[MS_EMAX];
   // filter f at output index k from y in LDS (the few samples the parabolas and crossing interpolations need)
   auto flt_at = [&](int f, int k) -> float {
     if (f < 3) {
@@ -844,55 +937,18 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     }
     return S.X[max(k, 1)] - S.X[max(k - 1, 0)];
   };
-  // in-trace pile-up threshold (dsp_routines.jl:75-77) and t50_current threshold (dsp_icpc.jl:192); their masks from the
-  // registers that hold the SG output (g = -inf beyond the output axis: bit 0)
-  float thr_intr, thr_sg50;
-  {
-    const float s1 = fold_partials<NW>(S.wsum + (W_SGB + 0) * NW, 0.f, [](float a, float b) { return a + b; });
-    const float s2 = fold_partials<NW>(S.wsum + (W_SGB + 1) * NW, 0.f, [](float a, float b) { return a + b; });
-    const float m_ = s1 * (float)P.sgbl.inv_n;
-    const float var_ = fmaxf(fmaf(s2, (float)P.sgbl.inv_n, -m_ * m_), 0.f);
-    thr_intr = __builtin_amdgcn_sqrtf(var_) * P.intrace_nsigma;
-    if (thr_intr == 0.f) thr_intr = 1.f;
-    thr_sg50 = ford_inv(S.sl->fmx[FX_G]) * 0.5f;
-    uint32_t wi[R], w5[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { wi[r] = s4_pack_word(nib_ge(g[r], thr_intr), lane); w5[r] = s4_pack_word(nib_ge(g[r], thr_sg50), lane); }
-    if ((lane & 7) == 7) {
-      uint32_t* bi_ = S.bm + M_INTR * NWORDS + 8 * wave + (lane >> 3);
-      uint32_t* b5_ = S.bm + M_SG50 * NWORDS + 8 * wave + (lane >> 3);
-#pragma unroll
-      for (int r = 0; r < R; ++r) { bi_[(NT / 8) * r] = wi[r]; b5_[(NT / 8) * r] = w5[r]; }
-    }
-  }
-  if (tid == (256 % NT)) {   // a lane of wave 4: signalstats of the pole-zero corrected tail
-    float s1 = 0.f, s2 = 0.f, sx = 0.f;
-    for (int ww = 0; ww < NW; ++ww) { s1 += S.wsum[(W_PZ + 0) * NW + ww]; s2 += S.wsum[(W_PZ + 1) * NW + ww]; sx += S.wsum[(W_PZ + 2) * NW + ww]; }
-    float tailmean, tailsigma, tailslope, tailoffset;
-    win_finish(s1, s2, sx, P.tail, S.misc[14], P.t_first, P.dt, &tailmean, &tailsigma, &tailslope, &tailoffset);
-    S.outv[C_tailmean] = tailmean; S.outv[C_tailsigma] = tailsigma; S.outv[C_tailslope] = tailslope; S.outv[C_tailoffset] = tailoffset;
-  }
-  if (tid == (384 % NT)) {   // a lane of wave 6: results of sweep B
-    float v; int i;
-    unpack_vi(S.sl->vi[VI_OPT], &v, &i);
-    S.outv[C_e_trap_max] = v; S.outv[C_t_trap_max] = P.t_first + P.dt * (float)(i + P.opt.flen - 1);
-    S.outv[C_e_10410] = ford_inv(S.sl->fmx[FX_F0]); S.outv[C_e_535] = ford_inv(S.sl->fmx[FX_F1]); S.outv[C_e_313] = ford_inv(S.sl->fmx[FX_F2]);
-    S.outv[C_e_10410_inv] = ford_inv(S.sl->fmx[FX_F0I]); S.outv[C_e_313_inv] = ford_inv(S.sl->fmx[FX_F2I]);   // trap(-y) = -trap(y)  (dsp_icpc.jl:199-204)
-  }
-  __syncthreads();   // the four masks are complete
-  STAMP(12); DSTOP(12);
   // Intersect scans on the bit-masks (thread <-> word), see icpc_lean.hip
   static_assert(2 * NWORDS == NT, "one t0 / inverted-t0 word per thread");
   if (P.t0_mintot <= 97 && P.intrace_mintot <= 32) {   // block-uniform
     const int q = tid / NWORDS, wd = tid % NWORDS;
     const uint32_t* b0 = S.bm + (M_T0 + q) * NWORDS;
     const bool has_i = tid < NWORDS;
-    const uint32_t* bi = S.bm + (has_i ? M_INTR : M_SG50) * NWORDS;
+    const uint32_t* bi2 = S.bm + (has_i ? M_INTR : M_SG50) * NWORDS;
     uint32_t t[5], u[3];
 #pragma unroll
     for (int k = 0; k < 5; ++k) t[k] = b0[min(max(wd + k - 1, 0), NWORDS - 1)];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) u[k] = bi[min(max(wd + k - 1, 0), NWORDS - 1)];
+    for (int k = 0; k < 3; ++k) u[k] = bi2[min(max(wd + k - 1, 0), NWORDS - 1)];
     asm volatile("" ::: "memory");
     if (wd == 0) { t[0] = 0u; u[0] = 0u; }
 #pragma unroll
@@ -926,8 +982,49 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       if (c) { atomicAdd(&S.sl->isum[IS_INTR], c); atomicMax(&S.sl->imax[0], f); }
     }
   }
+  // Confirmation of the five threshold candidates (see icpc_lean.hip): imin[q] = first QUAD with a sample at or above
+  // threshold q; lane q of every wave finds the sample, checks that it is not sample 0 and that the next tx_mintot - 1 samples
+  // stay at or above the threshold.  A trace that fails runs the general scan (bit-masks of y by ballot, run scan on the words).
+  int p_tx = 0x7fffffff;   // lane q < 5: first confirmed sample of threshold q
+  {
+    const int q = min(lane, 4);
+    const float thrq = e_maxl * ((q == 0) ? 0.1f : (q == 1) ? 0.5f : (q == 2) ? 0.8f : (q == 3) ? 0.9f : 0.99f);
+    const int qd = S.sl->imin[IM_TX0 + q];
+    bool ok = e_maxl > 0.f;
+    if (ok && qd != 0x7fffffff) {
+      const f4 v = *reinterpret_cast<const f4*>(&S.X[4 * qd]);
+      const int e = (v.x >= thrq) ? 0 : (v.y >= thrq) ? 1 : (v.z >= thrq) ? 2 : 3;
+      p_tx = 4 * qd + e;
+      ok = p_tx >= 1 && p_tx + P.tx_mintot <= L;
+      for (int j = 1; ok && j < P.tx_mintot; ++j) ok = S.X[p_tx + j] >= thrq;
+    }
+    if (__ballot(lane < 5 && !ok) != 0ull) {   // block-uniform
+      __syncthreads();
+      if (tid < 5) S.sl->imin[IM_TX0 + tid] = 0x7fffffff;
+      for (int m = 0; m < SP; ++m) {
+        const float yv = S.X[tid + NT * m];
+#pragma unroll
+        for (int qq = 0; qq < 5; ++qq) {
+          const unsigned long long b = __ballot(yv >= e_maxl * ((qq == 0) ? 0.1f : (qq == 1) ? 0.5f : (qq == 2) ? 0.8f : (qq == 3) ? 0.9f : 0.99f));
+          if (lane == 0) *reinterpret_cast<unsigned long long*>(&S.bm[(M_FB + qq) * NWORDS + (NT >> 5) * m + 2 * wave]) = b;
+        }
+      }
+      __syncthreads();
+      for (int j = tid; j < 5 * NWORDS; j += NT) {
+        const int qq = j / NWORDS, wd = j % NWORDS;
+        int c, f;
+        intersect_word(S.bm + (M_FB + qq) * NWORDS, wd, NWORDS, P.tx_mintot, &c, &f);
+        if (c) atomicMin(&S.sl->imin[IM_TX0 + qq], f);
+      }
+      __syncthreads();
+      p_tx = S.sl->imin[IM_TX0 + q];
+    }
+  }
+  STAMP(11); DSTOP(11);
   __syncthreads();
-  STAMP(13); DSTOP(13);
+  STAMP(12); DSTOP(12);
+
+  // ================================================================== round 5: crossings, estimators, finishing lanes
   // t50_current and the in-trace pile-up position: one wave (5, or the last), lanes 0..3 evaluate the four SG samples
   if (wave == min(5, NW - 1)) {
     const int intr_n = S.sl->isum[IS_INTR];
@@ -940,15 +1037,49 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     if (lane == 0) {
       const float tg_first = P.t_first + P.dt * (float)(P.sg_npts[0] - 1);   // trailing alignment (A1)
       float t50cur_us = 0.f, intr_x = NAN;
-      if (has50) t50cur_us = (tg_first + P.dt * ((float)(p - 1) + (thr_sg50 - yl5) / (yh5 - yl5))) * P.inv_unit_per_us;
+      if (has50) t50cur_us = (tg_first + P.dt * ((float)(p - 1) + (S.misc[MS_THR5] - yl5) / (yh5 - yl5))) * P.inv_unit_per_us;
       if (intr_n > 0) {   // reversed index pos' = ng-1-e; r[pos'-1] = g[e+1], r[pos'] = g[e]
         const int pr = ng - 1 - e;
         const float xl = tg_first + P.dt * (float)(pr - 1);
-        const float xr_ = (thr_intr - yli) * P.dt / (yhi - yli) + xl;
+        const float xr_ = (S.misc[MS_THRI] - yli) * P.dt / (yhi - yli) + xl;
         intr_x = (tg_first + P.dt * (float)(ng - 1)) - xr_;   // last(time) - x   (dsp_routines.jl:81)
       }
       S.outv[C_t50_current] = t50cur_us; S.outv[C_inTrace_intersect] = intr_x; S.outv[C_inTrace_n] = __int_as_float(intr_n);
     }
+  }
+  // finishing lanes: the window statistics from the per-wave partials, the results of sweep B (waves that have nothing else to do here)
+  if (tid == (64 * (4 % NW))) {   // signalstats(bl): sigma, slope, offset (dsp_icpc.jl:102)
+    float s = 0.f, s2 = 0.f, sx = 0.f;
+    for (int ww = 0; ww < NW; ++ww) { s += S.wred[ww]; s2 += S.wred[NW + ww]; sx += S.wred[2 * NW + ww]; }
+    float m_, blsigma, blslope, bloffset;
+    win_finish(s, s2, sx, P.bl, pv_bl, P.t_first, P.dt, &m_, &blsigma, &blslope, &bloffset);
+    const float blm = S.misc[MS_BLMEAN];
+    S.outv[C_blmean] = blm; S.outv[C_blsigma] = blsigma; S.outv[C_blslope] = blslope; S.outv[C_bloffset] = bloffset;
+    S.outv[C_e_max] = S.misc[MS_RAWMAX] - blm; S.outv[C_e_min] = S.misc[MS_RAWMIN] - blm;
+  }
+  if (tid == (64 * (4 % NW)) + 1 % NT) {   // tailstats -> (mean, sigma, tau)
+    float tail_mean = 0.f, tail_sigma = 0.f, tail_tau = 0.f;
+    if (S.sl->isum[IS_TAILBAD] == 0) {
+      float s1 = 0.f, s2 = 0.f, sx = 0.f, sl, of;
+      for (int ww = 0; ww < NW; ++ww) { s1 += S.wsum[(W_TAIL + 0) * NW + ww]; s2 += S.wsum[(W_TAIL + 1) * NW + ww]; sx += S.wsum[(W_TAIL + 2) * NW + ww]; }
+      win_finish(s1, s2, sx, P.tail, S.misc[MS_PVTL], P.t_first, P.dt, &tail_mean, &tail_sigma, &sl, &of);
+      tail_tau = -__builtin_amdgcn_rcpf(sl);
+    }
+    S.outv[C_tail_tau] = tail_tau; S.outv[C_tail_mean] = tail_mean; S.outv[C_tail_sigma] = tail_sigma;
+  }
+  if (tid == (64 * (6 % NW)) + 2 % NT) {   // signalstats of the pole-zero corrected tail
+    float s1 = 0.f, s2 = 0.f, sx = 0.f;
+    for (int ww = 0; ww < NW; ++ww) { s1 += S.wsum[(W_PZ + 0) * NW + ww]; s2 += S.wsum[(W_PZ + 1) * NW + ww]; sx += S.wsum[(W_PZ + 2) * NW + ww]; }
+    float tailmean, tailsigma, tailslope, tailoffset;
+    win_finish(s1, s2, sx, P.tail, S.misc[14], P.t_first, P.dt, &tailmean, &tailsigma, &tailslope, &tailoffset);
+    S.outv[C_tailmean] = tailmean; S.outv[C_tailsigma] = tailsigma; S.outv[C_tailslope] = tailslope; S.outv[C_tailoffset] = tailoffset;
+  }
+  if (tid == (64 * (6 % NW)) + 3 % NT) {   // results of sweep B
+    float v; int i;
+    unpack_vi(S.sl->vi[VI_OPT], &v, &i);
+    S.outv[C_e_trap_max] = v; S.outv[C_t_trap_max] = P.t_first + P.dt * (float)(i + P.opt.flen - 1);
+    S.outv[C_e_10410] = ford_inv(S.sl->fmx[FX_F0]); S.outv[C_e_535] = ford_inv(S.sl->fmx[FX_F1]); S.outv[C_e_313] = ford_inv(S.sl->fmx[FX_F2]);
+    S.outv[C_e_10410_inv] = ford_inv(S.sl->fmx[FX_F0I]); S.outv[C_e_313_inv] = ford_inv(S.sl->fmx[FX_F2I]);   // trap(-y) = -trap(y)  (dsp_icpc.jl:199-204)
   }
   // crossing positions (sample units, split int + frac); NaN -> 0 us (dsp_routines.jl:24,41).  Seven interpolations, one per
   // lane (q < 5: threshold q of y; 5: t0; 6: inverted t0), evaluated by every wave that uses a position.  The two values of the
@@ -961,7 +1092,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     const int p = (q < 5) ? p_tx : S.sl->imin[q];
     const bool has = (q < 5) ? p != 0x7fffffff : S.sl->isum[IS_T0 + q - 5] > 0;
     const float frac = (q == 0) ? 0.1f : (q == 1) ? 0.5f : (q == 2) ? 0.8f : (q == 3) ? 0.9f : 0.99f;
-    const float thr = (q < 5) ? e_max * frac : P.t0_thr;
+    const float thr = (q < 5) ? e_maxl * frac : P.t0_thr;
     float tl = 0.f, th = 0.f;   // lanes 5, 6: the t0 trapezoid at p - 1 and p
     if (wave == 1 % NW || wave == NW - 1) {   // the waves that use the t0 position (qdrift; the times)
       const TrapDev t0 = P.t0;
@@ -1010,9 +1141,9 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       if (lane == 0) S.outv[C_drift_time] = (t90 - t0u) * P.unit_per_us;
     }
   }
-  STAMP(14); DSTOP(14);
+  STAMP(13); DSTOP(13);
 
-  // ------------------------------------------------------------------------------------ phase 6: signal estimators
+  // ---- signal estimators
   {
     lds_float* eslot = S.misc + 4;
     if (wave == 0) {
@@ -1090,23 +1221,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       if (interior) v = extrema3points(em, e0, ep);
       if (lane < 12 && d == -1) S.outv[f == 0 ? C_a_sg : f == 1 ? C_a_60 : f == 2 ? C_a_100 : C_a_raw] = v;
     }
-    STAMP(15); DSTOP(15);
-  }
-  // for the CUSP / ZAC stage (d[i] = y[i] - a*y[i-1], Dp = y - y[0] + eps*T): the first sample, the sample before each quad, and
-  // the sum of the wave-row's samples before the quad (T of a quad = wave-row offset + that)
-  const float y0 = S.X[0];
-  float yprev[R], p0[R];
-  {
-    float tin[R], tt[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i0 = 4 * (tid + NT * r);
-      yprev[r] = (i0 > 0) ? S.X[i0 - 1] : 0.f;
-      const f2 t = y[r].xy + y[r].zw; tt[r] = t.x + t.y; tin[r] = tt[r];
-    }
-    LDSP_DPP_GROUP4("v_add_f32_dpp", tin[0], "v_add_f32_dpp", tin[1], "v_add_f32_dpp", tin[2], "v_add_f32_dpp", tin[3]);
-#pragma unroll
-    for (int r = 0; r < R; ++r) p0[r] = tin[r] - tt[r];
+    STAMP(14); DSTOP(14);
   }
   {
     lds_float* eslot = S.misc + 4;
@@ -1117,21 +1232,29 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       S.outv[C_lq] = eslot[2];
     }
   }
+  STAMP(15); DSTOP(15);
 
   // ------------------------------------------------------------------------------------ phase 7: CUSP / ZAC (dsp_icpc.jl:167-178)
   // Closed form (CUSP / ZAC): with d[i] = y[i] - a*y[i-1],
   //   out[k] = sc * ( sum_{j<=Lf-2} w[j] d[n-j] + w[Lf-1] y[k] ),  n = k+Lf-1,
   // w = sinh flanks + flat top (+ parabolas for ZAC) splits into a causal one-pole G, an anti-causal one-pole A, the prefix sum
   // Dp of d, and a double prefix sum of a sparse combination u of Dp; each is built in the S4 view, stored to X and read back
-  // lane-strided, two rows per step.  X takes them in turns:  Dp -> u -> PRF -> Dp -> G -> A  (ZAC), Dp -> G -> A (CUSP alone).
+  // lane-strided, two rows per step.  X takes them in turns:  Dp -> u -> PRF -> G -> A  (ZAC), Dp -> G -> A (CUSP alone).
   // y is still in the thread's registers (S4 view).
   f4 ysave[SEP ? R : 1];
   if constexpr (SEP) {
 #pragma unroll
     for (int r = 0; r < R; ++r) ysave[r] = y[r];
   }
-  const f4 hq = *reinterpret_cast<const f4*>(&S.scn[R * NW + 4 * wave]), lq4 = *reinterpret_cast<const f4*>(&S.scn[2 * R * NW + 4 * wave]);
-  const float hwT[R] = {hq.x, hq.y, hq.z, hq.w}, lwT[R] = {lq4.x, lq4.y, lq4.z, lq4.w};
+  const float y0 = S.misc[15];
+  float* hyl_cz = S.hy + 4 * NH * (R * NW + 1);
+  // the sample before each quad (d[i] = y[i] - a*y[i-1]): the previous lane's last one; lane 0: the previous wave-row's, from the table
+  auto y_before = [&](int r) {
+    float v;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(y[r].w));
+    if (lane == 0) v = (r * NW + wave > 0) ? hyl_cz[r * NW + wave] : 0.f;
+    return v;
+  };
   auto cz_pass = [&](auto wc_tag, auto wz_tag, const CuspZacDev& Z, const CuspZacDev& ZZ, const float cpiv) {
     constexpr bool WC = decltype(wc_tag)::value, WZ = decltype(wz_tag)::value;
     const int Lf = Z.Lf;
@@ -1150,9 +1273,17 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       const f2 e2 = splat(Z.eps), y02 = splat(y0);
       const float bf = (float)(4 * tid);
       const f2 l01 = splat(mec) * mk2(bf, bf + 1.f), l23 = splat(mec) * mk2(bf + 2.f, bf + 3.f);
+      // T of a quad = T at the wave-row's first sample (the row table - delta (i + c i (i+1) / 2)) + the sum of the wave-row's
+      // samples before the quad (a DPP scan of the quad sums) + the running sum inside the quad
+      float p0[R], tt[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const f2 t = y[r].xy + y[r].zw; tt[r] = t.x + t.y; p0[r] = tt[r]; }
+      LDSP_DPP_GROUP4("v_add_f32_dpp", p0[0], "v_add_f32_dpp", p0[1], "v_add_f32_dpp", p0[2], "v_add_f32_dpp", p0[3]);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        f4 t = t_quad(y[r], p0[r], hwT[r], lwT[r]);
+        const float fs = (float)wrow(r);
+        const float hw_ = S.scn[4 * wave + r], lw_ = S.scn[R * NW + 4 * wave + r] - S.misc[MS_DELTA] * (fs * fmaf(0.5f * P.pz_c, fs + 1.f, 1.f));
+        f4 t = t_quad(y[r], p0[r] - tt[r], hw_, lw_);
         const f2 lr = splat(mec * (float)(4 * NT * r));
         t.xy = fma2(e2, t.xy, y[r].xy - y02) + (l01 + lr);
         t.zw = fma2(e2, t.zw, y[r].zw - y02) + (l23 + lr);
@@ -1164,43 +1295,67 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     store_dp();
     __syncthreads();
     STAMP(16); DSTOP(16);
-    f2 dz[SP / 2];   // ZAC - CUSP: the parabola part (+ the difference of the last taps)
+    f2 ac[SP / 2];
+    // ---- flat top + last tap (LS).  The last tap multiplies y'[k] = Dp'[k] + (y0 - cpiv) - eps T'[k]; the host admits this kernel
+    // only where eps * |w_last| * (rail * L) is far below the columns' resolution (dsp_icpc sets tau = 1e7 us "to switch off CR",
+    // src/dsp_icpc.jl:98: eps = 1.6e-9) and the third term is dropped.
+    auto flat_top = [&]() {
+      const f2 wl = splat(Z.w_last), sc = splat(Z.sc);
+      const float yc = y0 - cpiv;
+      const f2 wlc = splat(Z.w_last * yc);
+      const float *dk = &S.X[tid], *dpa = &S.X[tid + Lf - 1 - lt], *dpb = &S.X[tid + Lf - 1 - f1];
 #pragma unroll
-    for (int m = 0; m < SP / 2; ++m) dz[m] = splat(0.f);
+      for (int m = 0; m < SP; m += 2) {
+        ac[m / 2] = splat(0.f);
+        if (NT * m >= nout) continue;   // row pair beyond the output range (block-uniform)
+        const f2 yk = rd2(dk, m), pa = rd2(dpa, m), pb = rd2(dpb, m);
+        ac[m / 2] = fma2(sc, pa - pb, fma2(wl, yk, wlc));
+        pin(ac[m / 2]);
+        if ((m & 2) == 2) __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    f2 dz[SP / 2];   // ZAC - CUSP: the parabola part (the difference of the last taps is folded into it)
     if constexpr (WZ) {
       // ---- u[n] = sum_e zc_r[e] (Dp[n - s_e] - Dp[n - s_{e+1}])  (LS) -> X in place of Dp
       {
         f2 u[SP / 2];
 #pragma unroll
         for (int m = 0; m < SP / 2; ++m) u[m] = splat(0.f);
-        if (ZZ.zc_n == 9) {   // (block-uniform) the usual tap structure: one chain, every shift read once, links unrolled
-          f2 prev[SP / 2];
+        // the chain of shifts s_0 < s_1 < ..: every shift read once, u += R_e (Dp[n - s_e] - Dp[n - s_{e+1}]).  When CUSP shares the pass
+        // (its last tap is the one the flat-top step applies) the chain has the parabola's last tap folded in (icpc_dev.hpp: zf_*)
+        const bool fold = WC && ZZ.zf_n > 0;
+        const int nch = fold ? ZZ.zf_n : ZZ.zc_n;
+        const int32_t* cs = fold ? ZZ.zf_s : ZZ.zc_s;
+        const float* cr = fold ? ZZ.zf_r : ZZ.zc_r;
+        // (two halves of the rows in turn: half the chain's registers — previous reads, reads in flight — at a time)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          constexpr int HP = SP / 4;   // row pairs per half
+          f2 prev[HP];
           {
-            const float* dp = &S.X[tid - ZZ.zc_s[0]];
+            const float* dp = &S.X[tid - cs[0]];
 #pragma unroll
-            for (int m = 0; m < SP; m += 2) prev[m / 2] = rd2(dp, m);
+            for (int m = 0; m < HP; ++m) prev[m] = rd2(dp, 2 * (HP * hf + m));
           }
+          auto link = [&](int e) {
+            const f2 ce = splat(cr[e]);
+            const float* dq = &S.X[tid - cs[e + 1]];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const f2 ce = splat(ZZ.zc_r[e]);
-            const float* dq = &S.X[tid - ZZ.zc_s[e + 1]];
-#pragma unroll
-            for (int m = 0; m < SP; m += 2) {
-              const f2 cur = rd2(dq, m);
-              u[m / 2] = fma2(ce, prev[m / 2] - cur, u[m / 2]);
-              prev[m / 2] = cur;
+            for (int m = 0; m < HP; ++m) {
+              const f2 cur = rd2(dq, 2 * (HP * hf + m));
+              u[HP * hf + m] = fma2(ce, prev[m] - cur, u[HP * hf + m]);
+              prev[m] = cur;
             }
-            pin(u[0]);
-          }
-        } else {
-          const int nz = ZZ.zu_n;
-          for (int e = 0; e < nz; ++e) {
-            const f2 ce = splat(ZZ.zu_coef[e]);
-            const float *dp = &S.X[tid - ZZ.zu_shift[e]], *dq = &S.X[tid - ZZ.zu_shift_b[e]];
+          };
+          if (nch == 9) {   // (block-uniform) the usual tap structure: links unrolled
 #pragma unroll
-            for (int m = 0; m < SP; m += 2) { u[m / 2] = fma2(ce, rd2(dp, m) - rd2(dq, m), u[m / 2]); pin(u[m / 2]); }
+            for (int e = 0; e < 8; ++e) link(e);
+          } else {
+            for (int e = 0; e + 1 < nch; ++e) link(e);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
+        flat_top();   // (after the chain: its sixteen accumulators are not alive across it)
         __syncthreads();   // every read of Dp is done
 #pragma unroll
         for (int m = 0; m < SP; m += 2) wr2(&S.X[tid], m, u[m / 2]);
@@ -1260,40 +1415,25 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       {
         const float* pr = &S.X[tid + Lf - 1];
 #pragma unroll
-        for (int m = 0; m < SP; m += 2) { if (NT * m >= nout) continue; dz[m / 2] = rd2(pr, m); pin(dz[m / 2]); }
+        for (int m = 0; m < SP; m += 2) { dz[m / 2] = splat(0.f); if (NT * m >= nout) continue; dz[m / 2] = rd2(pr, m); pin(dz[m / 2]); }
       }
-      __syncthreads();   // every read of PRF is done
-      store_dp();
-      __syncthreads();
       STAMP(18); DSTOP(18);
-    }
-    // ---- flat top + last tap (LS).  The last tap multiplies y'[k] = Dp'[k] + (y0 - cpiv) - eps T'[k]; the host admits this kernel
-    // only where eps * |w_last| * (rail * L) is far below the columns' resolution (dsp_icpc sets tau = 1e7 us "to switch off CR",
-    // src/dsp_icpc.jl:98: eps = 1.6e-9) and the third term is dropped.
-    f2 ac[SP / 2];
-    {
-      const f2 dwl = splat(ZZ.w_last - Z.w_last), wl = splat(Z.w_last), sc = splat(Z.sc);
-      const float yc = y0 - cpiv;
-      const f2 wlc = splat(Z.w_last * yc), dwlc = splat((ZZ.w_last - Z.w_last) * yc);
-      const float *dk = &S.X[tid], *dpa = &S.X[tid + Lf - 1 - lt], *dpb = &S.X[tid + Lf - 1 - f1];
+    } else {
+      flat_top();
 #pragma unroll
-      for (int m = 0; m < SP; m += 2) {
-        ac[m / 2] = splat(0.f);
-        if (NT * m >= nout) continue;   // row pair beyond the output range (block-uniform)
-        const f2 yk = rd2(dk, m), pa = rd2(dpa, m), pb = rd2(dpb, m);
-        ac[m / 2] = fma2(sc, pa - pb, fma2(wl, yk, wlc));
-        if constexpr (WZ) dz[m / 2] += fma2(dwl, yk, dwlc);
-        pin(ac[m / 2]);
-        if ((m & 2) == 2) __builtin_amdgcn_sched_barrier(0);
-      }
+      for (int m = 0; m < SP / 2; ++m) dz[m] = splat(0.f);
     }
     // ---- d[i] = (y[i]-y[i-1]) + eps*y[i-1] for 1 <= i < L, else 0   (S4)
     f2 d[R][2];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const f2 q0 = mk2(yprev[r], y[r].x), q1_ = mk2(y[r].y, y[r].z);
-      d[r][0] = fma2(splat(Z.eps), q0, (y[r].xy - q0) + splat(mec));
-      d[r][1] = fma2(splat(Z.eps), q1_, (y[r].zw - q1_) + splat(mec));
+      // (element by element: the odd-aligned pair (y1, y2) of a packed form is one the Savitzky-Golay pass also builds, and hipcc
+      // then keeps that pass's copies alive — in scratch — until here)
+      const float yb = y_before(r);
+      d[r][0].x = fmaf(Z.eps, yb, (y[r].x - yb) + mec);
+      d[r][0].y = fmaf(Z.eps, y[r].x, (y[r].y - y[r].x) + mec);
+      d[r][1].x = fmaf(Z.eps, y[r].y, (y[r].z - y[r].y) + mec);
+      d[r][1].y = fmaf(Z.eps, y[r].z, (y[r].w - y[r].z) + mec);
       if (r == 0 && tid == 0) d[0][0].x = 0.f;
     }
     STAMP(19); DSTOP(19);
@@ -1367,6 +1507,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     }
     STAMP(21); DSTOP(21);
     // ---- extremestats + SignalEstimator of both outputs (dsp_icpc.jl:170-171,177-178): value first, then its first index
+    const int tqf = opaque(tid);
     float mxc = -INFINITY, mxz = -INFINITY;
     float pc = 0.f, pz_ = 0.f;
     float own_c, own_z;
@@ -1375,7 +1516,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       for (int m = 0; m < SP; m += 2) {
         f2 a = ac[m / 2], z = dz[m / 2];
         if (NT * (m + 2) > nout) {
-          const bool in0 = tid + NT * m < nout, in1 = tid + NT * (m + 1) < nout;
+          const bool in0 = tqf + NT * m < nout, in1 = tqf + NT * (m + 1) < nout;
           a.x = in0 ? a.x : -INFINITY; a.y = in1 ? a.y : -INFINITY; z.x = in0 ? z.x : -INFINITY; z.y = in1 ? z.y : -INFINITY;
         }
         mxc = vmax3(mxc, a.x, a.y); mxz = vmax3(mxz, z.x, z.y);
@@ -1384,8 +1525,8 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       if (nout >= P.sig_est.npts) {
         const f4 ew = (f4){S.misc[8], S.misc[9], S.misc[10], S.misc[11]};   // i0 (bits) and u of the CUSP and of the ZAC estimate
         const int i0c = __float_as_int(ew.x), i0z = __float_as_int(ew.z);
-        const int msc = (i0c - tid + NT - 1) / NT, msz = (i0z - tid + NT - 1) / NT;   // smallest m with tid + NT*m >= i0
-        const int lc = tid + NT * msc - i0c, lz = tid + NT * msz - i0z;
+        const int msc = (i0c - tqf + NT - 1) / NT, msz = (i0z - tqf + NT - 1) / NT;   // smallest m with tid + NT*m >= i0
+        const int lc = tqf + NT * msc - i0c, lz = tqf + NT * msz - i0z;
         const bool inc_ = lc >= 0 && lc < P.sig_est.npts && msc >= 0 && msc < SP, inz = lz >= 0 && lz < P.sig_est.npts && msz >= 0 && msz < SP;
         if (__ballot(inc_ || inz) != 0ull) {
           float vc_ = 0.f, vz_ = 0.f;
@@ -1412,9 +1553,9 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
 #pragma unroll
         for (int m = SP - 1; m >= 0; --m) {   // findmax: first occurrence
           const float a = (m & 1) ? ac[m / 2].y : ac[m / 2].x, z = (m & 1) ? dz[m / 2].y : dz[m / 2].x;
-          const bool in = tid + NT * m < nout;
-          bc = (in && a == vc) ? tid + NT * m : bc;
-          bz = (in && z == vz) ? tid + NT * m : bz;
+          const bool in = tqf + NT * m < nout;
+          bc = (in && a == vc) ? tqf + NT * m : bc;
+          bz = (in && z == vz) ? tqf + NT * m : bz;
         }
         if (WC && bc != 0x7fffffff) atomicMin(&S.sl->imin[IM_CUSP], bc);
         if (WZ && bz != 0x7fffffff) atomicMin(&S.sl->imin[IM_ZAC], bz);
@@ -1428,7 +1569,8 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       for (int ww = 0; ww < NW; ++ww) s += S.wsum[(W_CZ + f) * NW + ww];
       const float v = ford_inv(S.sl->fmx[f ? FX_ZAC : FX_CUSP]);
       const int i = S.sl->imin[f ? IM_ZAC : IM_CUSP];
-      const double back = (double)cpiv * (f ? ZZ.hsum : Z.hsum);   // the pivot's share of the output (estimator weights sum to one)
+      double back = (double)cpiv * (f ? ZZ.hsum : Z.hsum);   // the pivot's share of the output (estimator weights sum to one)
+      if (f && WC && ZZ.zf_n > 0) back += (double)(ZZ.w_last - Z.w_last) * (double)(y0 - cpiv);   // ... and the folded last tap's constant
       S.outv[f ? C_e_zac : C_e_cusp] = (nout >= P.sig_est.npts) ? (float)((double)s + back) : NAN;
       S.outv[f ? C_e_zac_max : C_e_cusp_max] = (float)((double)v + back);
       S.outv[f ? C_t_zac_max : C_t_cusp_max] = P.t_first + P.dt * (float)(i + Lf - 1);

@@ -310,6 +310,29 @@ static bool make_cuspzac(const ldsp_cuspzac& p, bool zac, CuspZacDev& d) {
       if (e + 1 < terms.size()) d.zc_r[e] = (float)(std::fabs(rr) <= 1e-9 ? 0.0 : rr);
     }
   }
+  {   // the chain with the last tap folded in
+    std::vector<std::pair<int, double>> tf = terms;
+    const double pl = par[g.Lf - 1];
+    const std::pair<int, double> extra[3] = {{g.Lf - 1, pl}, {g.Lf, -2.0 * pl}, {g.Lf + 1, pl}};
+    for (auto& x : extra) {
+      bool found = false;
+      for (auto& t : tf) if (t.first == x.first) { t.second += x.second; found = true; }
+      if (!found) tf.push_back(x);
+    }
+    std::sort(tf.begin(), tf.end());
+    std::vector<std::pair<int, double>> tg;
+    for (auto& t : tf) if (std::fabs(t.second) > 1e-9) tg.push_back(t);
+    d.zf_n = 0;
+    if (tg.size() >= 2 && tg.size() <= 13) {
+      d.zf_n = (int)tg.size();
+      double rr = 0;
+      for (size_t e = 0; e < tg.size(); ++e) {
+        d.zf_s[e] = tg[e].first;
+        rr += tg[e].second;
+        if (e + 1 < tg.size()) d.zf_r[e] = (float)(std::fabs(rr) <= 1e-9 ? 0.0 : rr);
+      }
+    }
+  }
   for (size_t e = 0; e + 1 < terms.size(); ++e) {
     run += terms[e].second;
     if (std::fabs(run) <= 1e-9) continue;
@@ -433,6 +456,7 @@ static bool icpc_lean3_applies(const ldsp_ctx* c) {
   if (!c->icpc_lean3 || c->icpc_lean2 || !icpc_lean_applies(c) || H.NT > 512) return false;
   const double rail = std::max(std::fabs((double)H.sat_high), std::fabs((double)H.sat_low)) * (double)H.L;
   const double drop = std::max(std::fabs((double)H.cusp.w_last) * H.cusp.eps, std::fabs((double)H.zac.w_last) * H.zac.eps) * rail;
+  if (H.cz_shared && H.zac.zf_n <= 0) return false;   // (the chain of ZAC shifts with the last tap folded in: icpc_dev.hpp)
   return drop < 1e-2 && icpc_lean3_smem_bytes(H.NT, std::max(H.cusp.Lf, H.zac.Lf)) <= 80640;
 }
 

@@ -12,7 +12,7 @@ for L, dt, n, base in ((8192, 16.0, 65536, 80640),):
     wf = ldsp.synth.hpge_batch(n, L, device="cuda")
     out = torch.empty((n, 48), dtype=torch.float32, device="cuda")
     for lean2 in (0, 1):
-      ctx.set_option("icpc_lean2", lean2)
+      ctx.set_option("icpc_lean3", 1 - lean2)
       for pad in ((0, 10000, 30000, 60000) if not lean2 else (0, 60000)):
         ctx.set_option("dbg_lds_pad", pad)
         ts = []

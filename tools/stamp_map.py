@@ -36,11 +36,11 @@ lean = {0: "start", 1: "load, raw extremes, baseline sums", 2: "per-wave partial
         14: "threshold confirmation, crossings", 15: "estimators, parabolas (waves 0-3), to the barrier", 16: "barrier, CZ: Dp, d (+barrier)",
         17: "CZ: flat top + ZAC taps (summed by parts)", 18: "CZ: causal scan + readback", 19: "CZ: anti-causal scan + readback",
         20: "CZ: double cumsum + readback", 21: "CZ: maxima, estimator points", 22: "CZ: collect"}
-lean3 = {0: "start", 1: "load, raw extremes, baseline sums", 2: "per-wave partials + barrier", 3: "blmean, shift, tail sums, cumsum scan + barrier",
-         4: "pz offsets (wave 0) + barrier, pole-zero", 5: "threshold candidates, T scan (wave 0), T -> X + 3 barriers", 6: "sweep A (S4: t0 masks)",
-         7: "sweep B (4 trapezoids)", 8: "tail sums, sweep reductions + barrier", 9: "y -> X + barrier", 10: "SG pass (S4)",
-         11: "SG reductions, threshold confirmation + barrier", 12: "SG masks from registers, finishing lanes + barrier", 13: "run scans on the masks + barrier",
-         14: "t50_current / pile-up position, crossings", 15: "estimators, parabolas (waves 0-3)", 16: "yprev, p0, barrier, CZ: Dp -> X + barrier",
+lean3 = {0: "start", 1: "load, raw extremes, baseline sums, prefix scans of x'", 2: "barrier, row tables (wave 0) | blmean", 3: "barrier, y and T -> X, tail logs, candidates",
+         4: "barrier, sweep A (S4: t0 masks)", 5: "sweep B (4 trapezoids)", 6: "tail sums, SG pass (registers, DPP halo)", 7: "the round's reductions",
+         8: "barrier", 9: "y -> X, SG masks from registers", 10: "barrier", 11: "run scans on the masks, threshold confirmation", 12: "barrier",
+         13: "t50_current / pile-up position, finishing lanes, crossings", 14: "estimators, parabolas (waves 0-3)", 15: "yprev, p0, barrier",
+         16: "CZ: Dp -> X + barrier",
          17: "CZ: u (ZAC taps) -> X + 2 barriers", 18: "CZ: double cumsum -> X, readback, Dp -> X + 4 barriers", 19: "CZ: flat top, d",
          20: "CZ: causal scan + readback", 21: "CZ: anti-causal scan + readback", 22: "CZ: maxima, estimator points", 23: "CZ: collect"}
 kn = ctx.last_kernel_name()
