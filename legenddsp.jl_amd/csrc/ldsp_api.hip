@@ -25,6 +25,7 @@ size_t icpc_lean_smem_bytes(int NT, int Lf);
 hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, const IcpcDev* dP, const IcpcOutDev& out,
                              const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st);
 size_t icpc_lean3_smem_bytes(int NT, int Lf);
+hipError_t launch_pz_trap_lean3(const float* wf, int64_t n, int NT, bool u16, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 extern int g_dbg_lds_pad;
 hipError_t launch_pz_trap_lean(const float* wf, int64_t n, int NT, bool u16, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
@@ -153,6 +154,7 @@ int ldsp_ctx_set_option(ldsp_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "dbg_lds_pad")) { ldsp::g_dbg_lds_pad = (int)value; return LDSP_OK; }
   if (!strcmp(key, "icpc_lean2")) { c->icpc_lean2 = value != 0; return LDSP_OK; }
   if (!strcmp(key, "icpc_lean3")) { c->icpc_lean3 = value != 0; return LDSP_OK; }
+  if (!strcmp(key, "pz_lean3")) { c->pz_lean3 = value != 0; return LDSP_OK; }
   if (!strcmp(key, "icpc_generic")) { c->icpc_generic = value != 0; return LDSP_OK; }
   if (!strcmp(key, "icpc_r2")) { c->icpc_r2 = value != 0; c->icpc_valid = false; return LDSP_OK; }
   if (!strcmp(key, "dbg_stamps")) { c->dbg_stamps = reinterpret_cast<long long*>((uintptr_t)value); c->icpc_valid = false; return LDSP_OK; }
@@ -560,7 +562,13 @@ static int pz_trap_run_impl(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_
   if (rc) return rc;
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   const int nt_pz = c->icpc_host.R == 2 ? 512 : c->icpc_host.NT;   // pz_trap_kernel keeps 16 samples per thread
-  if (icpc_lean_applies(c)) {
+  // (pz_trap_lean3_kernel — the round-3 kernel's single exchange of partial sums, three barriers instead of six — is available
+  // through option "pz_lean3" and measured SLOWER, 146 M against 170 M waveforms/s: this sub-chain is bound by its ~400
+  // instructions per wave, and the merged prefix scans cost 100 more)
+  if (c->pz_lean3 && icpc_lean3_applies(c)) {
+    HIP_TRY(launch_pz_trap_lean3(wf, n, c->icpc_host.NT, in_u16, c->d_icpc, blmean, e_10410, c->stream));
+    c->last_kernel = "lean3::pz_trap_lean3_kernel";
+  } else if (icpc_lean_applies(c)) {
     HIP_TRY(launch_pz_trap_lean(wf, n, c->icpc_host.NT, in_u16, c->d_icpc, blmean, e_10410, c->stream));
     c->last_kernel = "lean::pz_trap_lean_kernel";
   } else {

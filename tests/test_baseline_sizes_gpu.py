@@ -38,9 +38,11 @@ def test_icpc_one_million_traces(orc):
     gpu = {k: v.cpu().numpy() for k, v in ldsp.table_columns(tab[idx]).items()}
     lines, worst = parity.compare(gpu, ora)
     assert worst <= 2 / 192, "\n".join(lines)
-    # config 2 on the same batch: the sub-chain's columns are the fused chain's, bit for bit
+    # config 2 on the same batch: the sub-chain's columns are the fused chain's — blmean bit for bit, e_10410 to the rounding of T
+    # (two orders of the same partial sums, tests/test_icpc_gpu.py::test_pz_trap_subchain_on_uint16_adc_counts)
     blmean, e10410 = ldsp.icpc_pz_trap_run(wf, p)
-    assert torch.equal(blmean, cols["blmean"]) and torch.equal(e10410, cols["e_10410"])
+    assert torch.equal(blmean, cols["blmean"])
+    assert bool(((e10410 - cols["e_10410"]).abs() <= 0.02 + 3e-6 * cols["e_10410"].abs()).all())
 
 
 def test_sipm_625k_traces(orc):

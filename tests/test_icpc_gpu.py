@@ -214,8 +214,8 @@ def test_threshold_crossings_with_spikes_before_the_pulse(orc, params):
 
 def test_separately_optimised_cusp_and_zac_run_in_the_lean_launch(orc):
     """pars_filter with different rise / flat-top times for CUSP and ZAC (what an optimisation campaign produces): the lean
-    kernel evaluates the two filters in two passes of its closed-form stage inside the SAME launch (y and T put back in
-    between); the generic path needs three launches.  Both against the oracle, and the launch really is the lean kernel."""
+    kernel evaluates the two filters in two passes of its closed-form stage inside the SAME launch (y kept in registers for
+    the second one); the generic path needs three launches.  Both against the oracle, and the launch really is the lean kernel."""
     us = ldsp.us
     pf = {"cusp": {"rt": 4.0 * us, "ft": 1.5 * us}, "zac": {"rt": 5.5 * us, "ft": 2.0 * us}}
     p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * us, pf, L, 0.0, 16.0)
@@ -224,7 +224,7 @@ def test_separately_optimised_cusp_and_zac_run_in_the_lean_launch(orc):
     host = wf.cpu().numpy()
     ora = orc.dsp_icpc(host, p, nthreads=16)
     ctx = ldsp.default_context()
-    for generic, name in ((0, "lean::icpc_lean_kernel"), (1, "icpc_kernel")):
+    for generic, name in ((0, "lean3::icpc_lean3_kernel"), (1, "icpc_kernel")):
         gpu = _run(wf, p, generic=generic)
         assert ctx.last_kernel_name() == name
         lines, worst = parity.compare(gpu, ora, wf=host, params=p, orc=orc)
@@ -252,7 +252,9 @@ def test_uint16_adc_counts_are_converted_by_the_kernel(params, generic, two_kern
 @pytest.mark.parametrize("length,dt", [(8192, 16.0), (8000, 16.0), (4096, 32.0)])
 def test_pz_trap_subchain_on_uint16_adc_counts(length, dt):
     """ldsp_icpc_pz_trap_run_u16: uint16 ADC counts give blmean / e_10410 of the same values passed as float32, bit for bit
-    (lean kernel at 8192 and 4096 samples, generic kernel at 8000), and they are the fused chain's columns."""
+    (lean kernel at 8192 and 4096 samples, generic kernel at 8000), and they are the fused chain's columns: blmean bit for bit;
+    e_10410 to the last bits (round 3: the fused chain takes T = prefix sum of the pole-zero output from ONE exchange of partial
+    sums, config 2's kernel from two — the same sums in another order, each rounded once at the magnitude of T, 1e7..1e8)."""
     cfg = ldsp.plumbing_icpc_config_4096() if length == 4096 else ldsp.reference_test_icpc_config()
     p = ldsp.lower_icpc(cfg, 500 * ldsp.us, {}, length, 0.0, dt)
     wf = ldsp.synth.hpge_batch(192, 8192, device="cuda", seed=43).round().clamp(0, 65535)
@@ -263,4 +265,6 @@ def test_pz_trap_subchain_on_uint16_adc_counts(length, dt):
     b = ldsp.icpc_pz_trap_run(wf16, p).cpu().numpy()
     assert np.array_equal(a, b)
     full = ldsp.table_columns(ldsp.icpc_run(wf16, p))
-    assert np.array_equal(b[0], full["blmean"].cpu().numpy()) and np.array_equal(b[1], full["e_10410"].cpu().numpy())
+    assert np.array_equal(b[0], full["blmean"].cpu().numpy())
+    e_full = full["e_10410"].cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(b[1] - e_full) <= 0.02 + 3e-6 * np.abs(e_full)), np.abs(b[1] - e_full).max()

@@ -1,0 +1,31 @@
+#!/bin/bash
+# tools/prof_phases_lds.sh OUT [LIB] — per-phase LDS pipe activity of icpc_lean3_kernel (diagnostic build with -DLDSP_DSTOP): one rocprofv3
+# PMC pass per stop, cumulative LDS instructions / LDS-active cycles / bank-conflict cycles per wave.  Run on the GPU box.
+set -eo pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$1
+export LDSP_HIP_LIB=$(readlink -f ${2:-$R/build/dev/libldsp_ds.so})
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+STOPS="1 2 3 4 5 6 7 9 11 13 14 15 16 17 18 19 20 21 22 0"
+for k in $STOPS; do
+  stop=$((100 + k)); [ $k = 0 ] && stop=0
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT -d $O/s$k -o p --output-format csv -- python3 $R/tools/prof_small.py 16384 icpc_lean3=1 dbg_stop=$stop > $O/s$k.log 2>&1 || true
+done
+python3 - <<PY
+import csv, collections, glob
+prev = None
+names = ("SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_LDS_ADDR_CONFLICT")
+print("%-6s " % "stop" + " ".join("%22s" % n for n in names) + "   (cumulative per wave; increments in parentheses)")
+for k in [int(x) for x in "$STOPS".split()]:
+    acc = collections.defaultdict(float)
+    for f in glob.glob("$O/s%d/**/*counter_collection.csv" % k, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "icpc_lean3_kernel" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]] += float(r["Counter_Value"])
+    w = acc["SQ_WAVES"] or 1
+    cur = [acc[c] / w for c in names]
+    inc = [a - b for a, b in zip(cur, prev)] if prev else cur
+    print("%-6s " % ("end" if k == 0 else k) + " ".join("%12.0f(%+8.0f)" % (a, b) for a, b in zip(cur, inc)))
+    prev = cur
+PY
