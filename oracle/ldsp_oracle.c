@@ -1,5 +1,5 @@
 /*
- * ldsp_oracle.c — CPU restatement (float64, plain C) of the LegendDSP.jl
+ * ldsp_oracle.c — CPU restatement (plain C; float64, or the reference's Float32-input typing with -DORC_F32) of the LegendDSP.jl
  * dsp_icpc / dsp_sipm hot path.  TEST INFRASTRUCTURE ONLY: it is the checker
  * for the HIP path (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline
  * leg).  Nothing in the product (legenddsp.jl_amd/) may call, link or import it.
@@ -33,6 +33,19 @@
 #define ORC_ERR_WINDOW (-2)
 #define ORC_ERR_ARG (-1)
 
+/* `real`: the element type of the traces and of everything the reference computes in float(eltype(input)).  The default build
+ * is Float64 throughout — the checker of tests/.  -DORC_F32 (libldsp_oracle_f32.so) restates what the reference does with
+ * Float32 input (SURVEY §8 "int/fp": samples, filter states and the sums of Y in Float32; the time axis, X sums, X*Y sums,
+ * filter taps' derivation and estimator weights in Float64, src/tailstats.jl:39-43): tests/parity.py measures with it how far a
+ * correct Float32 chain lies from the Float64 one, column by column, instead of arguing that envelope. */
+#ifdef ORC_F32
+typedef float real;
+#define RLOG(v) logf(v)
+#else
+typedef double real;
+#define RLOG(v) log(v)
+#endif
+
 /* Julia round(Int, x): round half to even. Default FP rounding mode. */
 static inline long rnd(double x) { return (long)nearbyint(x); }
 
@@ -40,12 +53,12 @@ static inline long rnd(double x) { return (long)nearbyint(x); }
 /* signalstats — RadiationDetectorDSP (not in /root/reference); restated as
  * src/tailstats.jl:22-72 without the log and with the offset line un-commented
  * (tailstats.jl:62), per assumption A6. */
-int orc_signalstats(const double* y, int n, int from, int until, double t_first, double dt,
+int orc_signalstats(const real* y, int n, int from, int until, double t_first, double dt,
                     double* mean, double* sigma, double* slope, double* offset) {
   if (!(0 <= from && from <= until && until <= n - 1)) return ORC_ERR_WINDOW;
-  double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+  double sx = 0, sxx = 0, sxy = 0; real sy = 0, syy = 0;   /* src/tailstats.jl:39-43: sums of Y in float(eltype(Y)), of X and X*Y in Float64 */
   for (int i = from; i <= until; ++i) {
-    double x = t_first + i * dt, v = y[i];
+    double x = t_first + i * dt; real v = y[i];
     sx += x; sxx = fma(x, x, sxx);
     sy += v; syy = fma(v, v, syy);
     sxy = fma(x, v, sxy);
@@ -61,14 +74,14 @@ int orc_signalstats(const double* y, int n, int from, int until, double t_first,
 }
 
 /* tailstats — src/tailstats.jl:13-72 */
-int orc_tailstats(const double* y, int n, int from, int until, double t_first, double dt,
+int orc_tailstats(const real* y, int n, int from, int until, double t_first, double dt,
                   double* mean, double* sigma, double* tau) {
   if (!(0 <= from && from <= until && until <= n - 1)) return ORC_ERR_WINDOW;
   for (int i = from; i <= until; ++i)
     if (y[i] <= 0) { *mean = 0; *sigma = 0; *tau = 0; return ORC_OK; } /* :27-33 */
-  double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+  double sx = 0, sxx = 0, sxy = 0; real sy = 0, syy = 0;
   for (int i = from; i <= until; ++i) {
-    double x = t_first + i * dt, v = log(y[i]);
+    double x = t_first + i * dt; real v = RLOG(y[i]);
     sx += x; sxx = fma(x, x, sxx);
     sy += v; syy = fma(v, v, syy);
     sxy = fma(x, v, sxy);
@@ -84,7 +97,7 @@ int orc_tailstats(const double* y, int n, int from, int until, double t_first, d
 }
 
 /* extremestats — src/extremestats.jl:25-40 (findmin/findmax: first occurrence) */
-int orc_extremestats(const double* y, int n, int from, int until, double t_first, double dt,
+int orc_extremestats(const real* y, int n, int from, int until, double t_first, double dt,
                      double* vmin, double* vmax, double* tmin, double* tmax) {
   if (!(0 <= from && from <= until && until <= n - 1)) return ORC_ERR_WINDOW;
   int imin = from, imax = from;
@@ -98,11 +111,11 @@ int orc_extremestats(const double* y, int n, int from, int until, double t_first
 }
 
 /* thresholdstats — src/thresholdstats.jl:19-41 (n == 0 -> NaN via inv(0)) */
-double orc_thresholdstats(const double* y, int n, double lo, double hi) {
-  double sy = 0, syy = 0; long cnt = 0;
+double orc_thresholdstats(const real* y, int n, double lo, double hi) {
+  real sy = 0, syy = 0; long cnt = 0;
   for (int i = 0; i < n; ++i) {
     int inc = (lo <= y[i] && y[i] <= hi);
-    double v = inc ? y[i] : 0.0;
+    real v = inc ? y[i] : (real)0;
     sy += v; syy = fma(v, v, syy); cnt += inc;
   }
   double inv_n = 1.0 / (double)cnt;
@@ -113,30 +126,30 @@ double orc_thresholdstats(const double* y, int n, double lo, double hi) {
 }
 
 static int cmp_dbl(const void* a, const void* b) {
-  double x = *(const double*)a, y = *(const double*)b;
+  real x = *(const real*)a, y = *(const real*)b;
   return (x > y) - (x < y);
 }
 /* Statistics.median: mean of the two middle order statistics for even counts */
-static double median_inplace(double* v, int m) {
-  qsort(v, (size_t)m, sizeof(double), cmp_dbl);
+static real median_inplace(real* v, int m) {
+  qsort(v, (size_t)m, sizeof(real), cmp_dbl);
   return (m & 1) ? v[m / 2] : 0.5 * (v[m / 2 - 1] + v[m / 2]);
 }
 /* thresholdstats_mad — src/thresholdstats.jl:61-71 */
-double orc_thresholdstats_mad(const double* y, int n, double lo, double hi) {
-  double* f = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+double orc_thresholdstats_mad(const real* y, int n, double lo, double hi) {
+  real* f = (real*)malloc(sizeof(real) * (size_t)(n > 0 ? n : 1));
   int m = 0;
   for (int i = 0; i < n; ++i)
     if (lo <= y[i] && y[i] <= hi) f[m++] = y[i];
   if (m == 0) { free(f); return 0.0; }
-  double med = median_inplace(f, m);
+  real med = median_inplace(f, m);
   for (int i = 0; i < m; ++i) f[i] = fabs(f[i] - med);
-  double r = 1.4826 * median_inplace(f, m);
+  double r = 1.4826 * (double)median_inplace(f, m);
   free(f);
   return r;
 }
 
 /* saturation — src/saturation.jl:28-65 */
-int orc_saturation(const double* y, int n, int from, int until, double low, double high, int out[4]) {
+int orc_saturation(const real* y, int n, int from, int until, double low, double high, int out[4]) {
   if (!(0 <= from && from <= until && until <= n - 1)) return ORC_ERR_WINDOW;
   int n_low = 0, n_high = 0, cons_low = 0, cons_high = 0, c_low = 0, c_high = 0;
   for (int i = from; i <= until; ++i) {
@@ -162,19 +175,19 @@ int orc_saturation(const double* y, int n, int from, int until, double low, doub
 }
 
 /* extrema3points — src/interpolation.jl:8-10 */
-static inline double extrema3points(double y1, double y2, double y3) {
-  double a = (y3 - 4 * y2 + 3 * y1);
+static inline real extrema3points(real y1, real y2, real y3) {
+  real a = (y3 - 4 * y2 + 3 * y1);
   return y1 - a * a / (8 * (y3 - 2 * y2 + y1));
 }
 /* argmax (first occurrence) + parabola if strictly interior — src/interpolation.jl:30-46 */
-static double window_max_interp(const double* y, int from, int until) {
+static real window_max_interp(const real* y, int from, int until) {
   int im = from;
   for (int i = from + 1; i <= until; ++i)
     if (y[i] > y[im]) im = i;
   if (from < im && im < until) return extrema3points(y[im - 1], y[im], y[im + 1]);
   return y[im];
 }
-int orc_get_wvf_maximum(const double* y, int n, int from, int until, double* out) {
+int orc_get_wvf_maximum(const real* y, int n, int from, int until, double* out) {
   if (!(0 <= from && from <= until && until <= n - 1)) return ORC_ERR_WINDOW;
   *out = window_max_interp(y, from, until);
   return ORC_OK;
@@ -185,7 +198,7 @@ int orc_get_wvf_maximum(const double* y, int n, int from, int until, double* out
  * Restated as the scan of src/intersect_maximum.jl:41-56 / src/multi_intersect.jl:53-72
  * keeping only the first confirmed crossing and counting all.
  * Time axis may be non-uniform-free: x(i) = t_first + i*dt. */
-void orc_intersect(const double* y, int n, double t_first, double dt, double thr, int min_n,
+void orc_intersect(const real* y, int n, double t_first, double dt, double thr, int min_n,
                    double* xout, int* mult) {
   if (n <= 0) { *xout = NAN; *mult = 0; return; }
   int cand = 1, pos = 1, cnt = (y[0] >= thr) ? min_n + 1 : 0, nint = 0;
@@ -200,7 +213,7 @@ void orc_intersect(const double* y, int n, double t_first, double dt, double thr
   }
   if (nint > 0 && pos > 0) {
     double xl = t_first + (pos - 1) * dt, xr = t_first + pos * dt;
-    double yl = y[pos - 1], yr = y[pos];
+    real yl = y[pos - 1], yr = y[pos];
     *xout = (thr - yl) * (xr - xl) / (yr - yl) + xl;
   } else {
     *xout = NAN;
@@ -210,7 +223,7 @@ void orc_intersect(const double* y, int n, double t_first, double dt, double thr
 
 /* IntersectMaximum — src/intersect_maximum.jl:24-119.  Returns multiplicity;
  * fills at most cap entries of each output. */
-int orc_intersect_maximum(const double* y, int n, double t_first, double dt, double thr,
+int orc_intersect_maximum(const real* y, int n, double t_first, double dt, double thr,
                           int min_n, int max_n, int cap, double* x, double* x_high,
                           double* x_tot, double* vmax) {
   if (n <= 0) return 0; /* :30-38 */
@@ -226,18 +239,18 @@ int orc_intersect_maximum(const double* y, int n, double t_first, double dt, dou
   for (int k = 0; k < nup && k < cap; ++k) {
     int up = ups[k];
     double xl = t_first + (up - 1) * dt, xr = t_first + up * dt;
-    double yl = y[up - 1], yr = y[up];
+    real yl = y[up - 1], yr = y[up];
     double xi = (thr - yl) * (xr - xl) / (yr - yl) + xl; /* :71 */
     int from = up - 2 > 0 ? up - 2 : 0;                  /* :75 */
     int until = up + max_n < n - 1 ? up + max_n : n - 1; /* :76 */
-    double mx = window_max_interp(y, from, until);       /* :79-85 */
+    real mx = window_max_interp(y, from, until);       /* :79-85 */
     int down = -1;
     for (int j = up + min_n; j < n; ++j) /* :90-95 */
       if (y[j] < thr) { down = j; break; }
     double xh;
     if (down > 0) { /* :99 */
       double dxl = t_first + (down - 1) * dt, dxr = t_first + down * dt;
-      double dyl = y[down - 1], dyr = y[down];
+      real dyl = y[down - 1], dyr = y[down];
       xh = (thr - dyl) * (dxr - dxl) / (dyr - dyl) + dxl;
     } else {
       xh = t_first + (n - 1) * dt; /* :106 */
@@ -329,7 +342,7 @@ int orc_sg_coeffs(int npts, int degree, int deriv, double* h) {
  * Assumption A3: LSQ polynomial of `degree` over the npts samples nearest-centred
  * on t, window clamped inside the trace, evaluated at the fractional sample
  * position of t (itself clamped to the trace). */
-int orc_signal_estimator(const double* y, int n, double t_first, double dt, double t,
+int orc_signal_estimator(const real* y, int n, double t_first, double dt, double t,
                          int npts, int degree, double* out) {
   if (npts > n || npts <= degree || npts < 1) { *out = NAN; return ORC_ERR_ARG; }
   double p = (t - t_first) / dt;
@@ -367,11 +380,11 @@ int orc_signal_estimator(const double* y, int n, double t_first, double dt, doub
 
 /* MultiIntersect — src/multi_intersect.jl:36-104.  Returns 0, or ORC_ERR_WINDOW
  * where the reference's boundary @assert (:75-78) fires. */
-int orc_multi_intersect(const double* y, int n, double t_first, double dt, const double* ratios,
+int orc_multi_intersect(const real* y, int n, double t_first, double dt, const double* ratios,
                         int K, int min_n, int half_n, int degree, int rate, double* xout) {
   for (int k = 0; k < K; ++k) xout[k] = 0;
   if (n <= 0) return ORC_OK; /* :50 */
-  double ymax = y[0];
+  real ymax = y[0];
   for (int i = 1; i < n; ++i)
     if (y[i] > ymax) ymax = y[i];
   double* thr = (double*)malloc(sizeof(double) * (size_t)K);
@@ -393,7 +406,7 @@ int orc_multi_intersect(const double* y, int n, double t_first, double dt, const
   if (rc == ORC_OK) {
     int w = 2 * half_n, m = 2 * half_n * rate, d1 = degree + 1;
     double* B = (double*)malloc(sizeof(double) * (size_t)w * (size_t)d1);
-    double* yup = (double*)malloc(sizeof(double) * (size_t)m);
+    real* yup = (real*)malloc(sizeof(real) * (size_t)m);
     double c, s;
     if (lsq_basis(w, degree, B, &c, &s)) rc = ORC_ERR_ARG;
     for (int k = 0; k < K && rc == ORC_OK; ++k) {
@@ -427,28 +440,28 @@ int orc_multi_intersect(const double* y, int n, double t_first, double dt, const
 /* InvCRFilter(tau) — RadiationDetectorDSP biquad b=(k,-1,0), a=(1,-1,0),
  * k = 1 + dt/tau, zero initial state (assumption A5):
  * y[n] = y[n-1] + k x[n] - x[n-1]. */
-int orc_invcr(const double* x, int n, double c, double* y) {
-  double k = 1.0 + c, yp = 0, xp = 0;
+int orc_invcr(const real* x, int n, double c, real* y) {
+  real k = (real)(1.0 + c), yp = 0, xp = 0;
   for (int i = 0; i < n; ++i) { yp = yp + k * x[i] - xp; xp = x[i]; y[i] = yp; }
   return n;
 }
 /* IntegratorFilter(gain) — biquad b=(g,0,0), a=(1,-1,0) */
-int orc_integrator(const double* x, int n, double gain, double* y) {
-  double acc = 0;
+int orc_integrator(const real* x, int n, double gain, real* y) {
+  real acc = 0;
   for (int i = 0; i < n; ++i) { acc += gain * x[i]; y[i] = acc; }
   return n;
 }
 /* TrapezoidalChargeFilter — RadiationDetectorDSP (assumption A1):
  * out[k] = mean(x[k+navg+ngap .. +navg2-1]) - mean(x[k .. k+navg-1]), valid mode. */
-int orc_trap(const double* x, int n, int navg, int ngap, int navg2, double* y) {
+int orc_trap(const real* x, int n, int navg, int ngap, int navg2, real* y) {
   int flen = navg + ngap + navg2;
   if (navg < 1 || navg2 < 1 || ngap < 0) return ORC_ERR_ARG;
   int nout = n - flen + 1;
   if (nout < 1) return ORC_ERR_WINDOW;
-  double s1 = 0, s2 = 0;
+  real s1 = 0, s2 = 0;
   for (int i = 0; i < navg; ++i) s1 += x[i];
   for (int i = 0; i < navg2; ++i) s2 += x[navg + ngap + i];
-  double i1 = 1.0 / navg, i2 = 1.0 / navg2;
+  real i1 = (real)(1.0 / navg), i2 = (real)(1.0 / navg2);
   y[0] = s2 * i2 - s1 * i1;
   for (int k = 1; k < nout; ++k) {
     s1 += x[k + navg - 1] - x[k - 1];
@@ -458,19 +471,19 @@ int orc_trap(const double* x, int n, int navg, int ngap, int navg2, double* y) {
   return nout;
 }
 /* Valid-mode true convolution y[k] = sum_j h[j] x[k+m-1-j] (ConvolutionFilter) */
-int orc_fir(const double* x, int n, const double* h, int m, double* y) {
+int orc_fir(const real* x, int n, const double* h, int m, real* y) {
   int nout = n - m + 1;
   if (m < 1) return ORC_ERR_ARG;
   if (nout < 1) return ORC_ERR_WINDOW;
-  double* hr = (double*)malloc(sizeof(double) * (size_t)m);
+  real* hr = (real*)malloc(sizeof(real) * (size_t)m);
   for (int j = 0; j < m; ++j) hr[j] = h[m - 1 - j];
   /* tap-outer / output-inner: each y[k] still accumulates its taps in ascending
    * order, but the inner loop vectorises across outputs */
   for (int k = 0; k < nout; ++k) y[k] = 0;
   for (int j = 0; j < m; ++j) {
-    const double hj = hr[j];
-    const double* restrict xp = x + j;
-    double* restrict yp = y;
+    const real hj = hr[j];
+    const real* restrict xp = x + j;
+    real* restrict yp = y;
     for (int k = 0; k < nout; ++k) yp[k] += hj * xp[k];
   }
   free(hr);
@@ -521,7 +534,7 @@ int orc_zac_coeffs(const ldsp_cuspzac* p, double* h) {
   return ORC_OK;
 }
 /* DerivativeFilter — src/derivative.jl:47-55 */
-int orc_derivative(const double* x, int n, double gain, double* y) {
+int orc_derivative(const real* x, int n, double gain, real* y) {
   for (int i = 0; i < n; ++i) {
     int a = i > 1 ? i : 1, b = i - 1 > 0 ? i - 1 : 0;
     if (a > n - 1) a = n - 1; /* n == 1: the reference would index out of bounds */
@@ -530,10 +543,10 @@ int orc_derivative(const double* x, int n, double gain, double* y) {
   return n;
 }
 /* HaarAveragingFilter — src/haar_filter.jl:26-39 */
-int orc_haar(const double* x, int n, int ds, double* y) {
+int orc_haar(const real* x, int n, int ds, real* y) {
   if (ds < 1) return ORC_ERR_ARG;
   int nout = (n + ds - 1) / ds;
-  double inv = 1.0 / sqrt(2.0);
+  real inv = 1.0 / sqrt(2.0);
   for (int i = 0; i < nout; ++i) {
     int s = i * ds, e = s + 1 < n ? s + 1 : n - 1;
     y[i] = (x[s] + x[e]) * inv;
@@ -541,9 +554,9 @@ int orc_haar(const double* x, int n, int ds, double* y) {
   return nout;
 }
 /* MovingWindowFilter — src/moving_window_multi.jl:99-116 */
-int orc_moving_window(const double* x, int n, int l, double* y) {
+int orc_moving_window(const real* x, int n, int l, real* y) {
   if (l < 1 || n < 1) return ORC_ERR_ARG;
-  double x1 = x[0], invl = 1.0 / l;
+  real x1 = x[0], invl = (real)(1.0 / l);
   y[0] = x1;
   for (int i = 1; i < l && i < n; ++i) y[i] = fma(invl, x[i] - x1, y[i - 1]);
   for (int i = l; i < n; ++i) y[i] = fma(invl, x[i] - x[i - l], y[i - 1]);
@@ -551,10 +564,10 @@ int orc_moving_window(const double* x, int n, int l, double* y) {
 }
 /* MovingWindowMultiFilter — src/moving_window_multi.jl:118-129:
  * fwd(x) -> _y; fwd on reversed _y, written reversed into y; fwd(y) -> y */
-int orc_moving_window_multi(const double* x, int n, int l, double* y) {
+int orc_moving_window_multi(const real* x, int n, int l, real* y) {
   if (l < 1 || n < 1) return ORC_ERR_ARG;
-  double* a = (double*)malloc(sizeof(double) * (size_t)n);
-  double* b = (double*)malloc(sizeof(double) * (size_t)n);
+  real* a = (real*)malloc(sizeof(real) * (size_t)n);
+  real* b = (real*)malloc(sizeof(real) * (size_t)n);
   orc_moving_window(x, n, l, a);
   for (int i = 0; i < n; ++i) b[i] = a[n - 1 - i];
   orc_moving_window(b, n, l, a);
@@ -568,8 +581,8 @@ int orc_moving_window_multi(const double* x, int n, int l, double* y) {
 /* L3 helpers — src/dsp_routines.jl */
 
 /* get_t0 — src/dsp_routines.jl:9-25; returns us, NaN -> 0 */
-static int get_t0(const double* y, int n, double t_first, double dt, double upus, ldsp_trap tr,
-                  double thr, int mintot, double* scratch, double* t0) {
+static int get_t0(const real* y, int n, double t_first, double dt, double upus, ldsp_trap tr,
+                  double thr, int mintot, real* scratch, double* t0) {
   int no = orc_trap(y, n, tr.navg, tr.ngap, tr.navg2, scratch);
   if (no < 0) return no;
   double tf = t_first + (tr.navg + tr.ngap + tr.navg2 - 1) * dt; /* A1: trailing alignment */
@@ -580,14 +593,14 @@ static int get_t0(const double* y, int n, double t_first, double dt, double upus
   return ORC_OK;
 }
 /* get_threshold — src/dsp_routines.jl:33-42 */
-static double get_threshold(const double* y, int n, double t_first, double dt, double upus, double thr, int mintot) {
+static double get_threshold(const real* y, int n, double t_first, double dt, double upus, double thr, int mintot) {
   double x; int mult;
   orc_intersect(y, n, t_first, dt, thr, mintot, &x, &mult);
   x /= upus;
   return (x != x) ? 0.0 : x;
 }
 /* get_qdrift — src/dsp_routines.jl:51-64 (integ = IntegratorFilter(1)(wvfs), precomputed) */
-static double get_qdrift(const double* integ, int n, double t_first, double dt, double t_start,
+static double get_qdrift(const real* integ, int n, double t_first, double dt, double t_start,
                          double d1, double d2, ldsp_dni est) {
   double e0, e1, e2;
   orc_signal_estimator(integ, n, t_first, dt, t_start, est.npts, est.degree, &e0);
@@ -614,16 +627,16 @@ enum {
 };
 
 typedef struct {
-  double *x, *y, *integ, *flt, *neg, *sg, *hc, *hz, *hsg[3];
+  real *x, *y, *integ, *flt, *neg, *sg; double *hc, *hz, *hsg[3];
 } icpc_ws;
 
 static int icpc_one(const float* wf, const ldsp_icpc_params* p, icpc_ws* w, double* o) {
   const int L = p->L;
   const double t0f = p->t_first, dt = p->dt, up = p->unit_per_us;
-  double* x = w->x; double* y = w->y;
+  real* x = w->x; real* y = w->y;
   int rc;
   for (int i = 0; i < C_NCOLS; ++i) o[i] = NAN;
-  for (int i = 0; i < L; ++i) x[i] = (double)wf[i];
+  for (int i = 0; i < L; ++i) x[i] = (real)wf[i];
 
   int sat[4]; /* :93-95 */
   if ((rc = orc_saturation(x, L, 0, L - 1, p->sat_low, p->sat_high, sat))) return rc;
@@ -632,7 +645,7 @@ static int icpc_one(const float* wf, const ldsp_icpc_params* p, icpc_ws* w, doub
   /* :102 */
   if ((rc = orc_signalstats(x, L, p->bl_from, p->bl_until, t0f, dt, &o[C_blmean], &o[C_blsigma], &o[C_blslope], &o[C_bloffset]))) return rc;
   for (int i = 0; i < L; ++i) x[i] -= o[C_blmean]; /* :105 */
-  double wmax = x[0], wmin = x[0];                  /* :111-112 */
+  real wmax = x[0], wmin = x[0];                  /* :111-112 */
   for (int i = 1; i < L; ++i) { if (x[i] > wmax) wmax = x[i]; if (x[i] < wmin) wmin = x[i]; }
   o[C_e_max] = wmax; o[C_e_min] = wmin;
   /* :115 */
@@ -658,7 +671,7 @@ static int icpc_one(const float* wf, const ldsp_icpc_params* p, icpc_ws* w, doub
   for (int f = 0; f < 3; ++f) {
     int no = orc_trap(y, L, p->trap_fixed[f].navg, p->trap_fixed[f].ngap, p->trap_fixed[f].navg2, w->flt);
     if (no < 0) return no;
-    double m = w->flt[0];
+    real m = w->flt[0];
     for (int i = 1; i < no; ++i) if (w->flt[i] > m) m = w->flt[i];
     o[cols_fixed[f]] = m;
   }
@@ -716,7 +729,7 @@ static int icpc_one(const float* wf, const ldsp_icpc_params* p, icpc_ws* w, doub
     o[C_inTrace_intersect] = (tf + (no - 1) * dt) - xr; /* :81, NaN stays NaN */
     o[C_inTrace_n] = mult;
     /* :192-195 */
-    double gmax = w->sg[0];
+    real gmax = w->sg[0];
     for (int i = 1; i < no; ++i) if (w->sg[i] > gmax) gmax = w->sg[i];
     o[C_t50_current] = get_threshold(w->sg, no, tf, dt, up, gmax * 0.5, p->tx_mintot);
   }
@@ -724,7 +737,7 @@ static int icpc_one(const float* wf, const ldsp_icpc_params* p, icpc_ws* w, doub
   for (int i = 0; i < L; ++i) w->neg[i] = y[i] * -1.0;
   {
     int no = orc_trap(w->neg, L, p->trap_fixed[0].navg, p->trap_fixed[0].ngap, p->trap_fixed[0].navg2, w->flt);
-    double m = w->flt[0];
+    real m = w->flt[0];
     for (int i = 1; i < no; ++i) if (w->flt[i] > m) m = w->flt[i];
     o[C_e_10410_inv] = m;
     no = orc_trap(w->neg, L, p->trap_fixed[2].navg, p->trap_fixed[2].ngap, p->trap_fixed[2].navg2, w->flt);
@@ -738,8 +751,8 @@ static int icpc_one(const float* wf, const ldsp_icpc_params* p, icpc_ws* w, doub
 
 static int icpc_ws_alloc(const ldsp_icpc_params* p, icpc_ws* w) {
   size_t L = (size_t)p->L;
-  w->x = (double*)malloc(8 * L); w->y = (double*)malloc(8 * L); w->integ = (double*)malloc(8 * L);
-  w->flt = (double*)malloc(8 * L); w->neg = (double*)malloc(8 * L); w->sg = (double*)malloc(8 * L);
+  w->x = (real*)malloc(sizeof(real) * L); w->y = (real*)malloc(sizeof(real) * L); w->integ = (real*)malloc(sizeof(real) * L);
+  w->flt = (real*)malloc(sizeof(real) * L); w->neg = (real*)malloc(sizeof(real) * L); w->sg = (real*)malloc(sizeof(real) * L);
   w->hc = (double*)malloc(8 * (size_t)p->cusp.length); w->hz = (double*)malloc(8 * (size_t)p->zac.length);
   int rc = orc_cusp_coeffs(&p->cusp, w->hc);
   if (!rc) rc = orc_zac_coeffs(&p->zac, w->hz);
@@ -791,12 +804,12 @@ int orc_dsp_icpc(const float* wf, long n, const ldsp_icpc_params* p, double* out
  * (src/dsp_icpc.jl:102-105,119-120,147-148). out [n][2] = (blmean, e_10410). */
 int orc_icpc_pz_trap(const float* wf, long n, const ldsp_icpc_params* p, double* out) {
   int L = p->L;
-  double* x = (double*)malloc(8 * (size_t)L);
-  double* y = (double*)malloc(8 * (size_t)L);
-  double* f = (double*)malloc(8 * (size_t)L);
+  real* x = (real*)malloc(sizeof(real) * (size_t)L);
+  real* y = (real*)malloc(sizeof(real) * (size_t)L);
+  real* f = (real*)malloc(sizeof(real) * (size_t)L);
   int rc = ORC_OK;
   for (long i = 0; i < n && !rc; ++i) {
-    for (int k = 0; k < L; ++k) x[k] = (double)wf[(size_t)i * L + k];
+    for (int k = 0; k < L; ++k) x[k] = (real)wf[(size_t)i * L + k];
     double m, s, sl, of;
     rc = orc_signalstats(x, L, p->bl_from, p->bl_until, p->t_first, p->dt, &m, &s, &sl, &of);
     if (rc) break;
@@ -804,7 +817,7 @@ int orc_icpc_pz_trap(const float* wf, long n, const ldsp_icpc_params* p, double*
     orc_invcr(x, L, p->pz_c, y);
     int no = orc_trap(y, L, p->trap_fixed[0].navg, p->trap_fixed[0].ngap, p->trap_fixed[0].navg2, f);
     if (no < 0) { rc = no; break; }
-    double mx = f[0];
+    real mx = f[0];
     for (int k = 1; k < no; ++k) if (f[k] > mx) mx = f[k];
     out[2 * i] = m; out[2 * i + 1] = mx;
   }
@@ -824,13 +837,13 @@ enum {
 };
 int orc_sipm_ncols(void) { return S_NCOLS; }
 
-static int sipm_one(const float* wf, const ldsp_sipm_params* p, double* ws, const double* hsg,
+static int sipm_one(const float* wf, const ldsp_sipm_params* p, real* ws, const double* hsg,
                     double* o, double* trig, int* counts, int cap) {
   const int L = p->L;
   const double t0f = p->t_first, dt = p->dt, up = p->unit_per_us;
-  double *x = ws, *g = ws + L, *I = ws + 2 * L, *F = ws + 3 * L, *P = ws + 4 * L, *T = ws + 5 * L;
+  real *x = ws, *g = ws + L, *I = ws + 2 * L, *F = ws + 3 * L, *P = ws + 4 * L, *T = ws + 5 * L;
   int rc;
-  for (int i = 0; i < L; ++i) x[i] = (double)wf[i] + 0.0; /* :88 */
+  for (int i = 0; i < L; ++i) x[i] = (real)wf[i] + (real)0; /* :88 */
   double vmin, vmax, tmin, tmax;
   if ((rc = orc_extremestats(x, L, 0, L - 1, t0f, dt, &vmin, &vmax, &tmin, &tmax))) return rc; /* :91 */
   o[S_e_min] = vmin; o[S_e_max] = vmax; o[S_t_min] = tmin / up; o[S_t_max] = tmax / up;
@@ -893,7 +906,7 @@ int orc_dsp_sipm(const float* wf, long n, const ldsp_sipm_params* p, double* out
 #pragma omp parallel num_threads(nthreads)
 #endif
   {
-    double* ws = (double*)malloc(8 * (size_t)p->L * 6);
+    real* ws = (real*)malloc(sizeof(real) * (size_t)p->L * 6);
     double* hsg = (double*)malloc(8 * (size_t)(p->sg_npts > 0 ? p->sg_npts : 1));
     int rc0 = orc_sg_coeffs(p->sg_npts, p->sg_degree, 1, hsg);
 #ifdef _OPENMP

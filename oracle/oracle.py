@@ -14,16 +14,29 @@ from legenddsp_jl_amd import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libldsp_oracle.so")
+_SO32 = os.path.join(_HERE, "libldsp_oracle_f32.so")   # -DORC_F32: the reference's typing for Float32 input (dsp_icpc only)
 
 
 def build(force=False):
     src = os.path.join(_HERE, "ldsp_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    if force or not os.path.exists(_SO) or not os.path.exists(_SO32) or min(os.path.getmtime(_SO), os.path.getmtime(_SO32)) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
 
 _lib = None
+_lib32 = None
+
+
+def lib32():
+    """The Float32-typed build (see the `real` typedef in ldsp_oracle.c): only orc_dsp_icpc is meant to be called through it —
+    the functor-level entry points of that build take float arrays."""
+    global _lib32
+    if _lib32 is None:
+        if not os.path.exists(_SO32):
+            build()
+        _lib32 = C.CDLL(_SO32)
+    return _lib32
 
 
 def lib():
@@ -190,15 +203,17 @@ def sg_coeffs(npts, degree, deriv):
 
 # ---- fused routines -----------------------------------------------------------
 
-def dsp_icpc(wf, params: _abi.IcpcParams, nthreads=1, strict=True):
-    """wf: [n][L] float32 -> dict of float64 columns in _abi.ICPC_COLS order."""
+def dsp_icpc(wf, params: _abi.IcpcParams, nthreads=1, strict=True, f32=False):
+    """wf: [n][L] float32 -> dict of float64 columns in _abi.ICPC_COLS order.  f32: the Float32-typed restatement (what the
+    reference computes for Float32 input), for the per-column float32 envelope of tests/parity.py."""
     wf = np.ascontiguousarray(wf, dtype=np.float32)
     n, L = wf.shape
     assert L == params.L
-    nc = lib().orc_icpc_ncols()
+    L_ = lib32() if f32 else lib()
+    nc = L_.orc_icpc_ncols()
     assert nc == len(_abi.ICPC_COLS)
     out = np.empty((n, nc)); status = np.zeros(n, dtype=np.int32)
-    rc = lib().orc_dsp_icpc(_p(wf), C.c_long(n), C.byref(params), _p(out), _p(status), int(nthreads))
+    rc = L_.orc_dsp_icpc(_p(wf), C.c_long(n), C.byref(params), _p(out), _p(status), int(nthreads))
     if strict:
         _chk(rc)
     cols = {c: out[:, i].copy() for i, c in enumerate(_abi.ICPC_COLS)}

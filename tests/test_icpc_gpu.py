@@ -51,11 +51,38 @@ def test_icpc_matches_oracle_seeded_batch(orc, params, direct, generic):
     assert worst <= parity.FLIP_FRAC, "\n".join(lines)
 
 
-def test_reference_fake_waveform_properties(params):
+def test_float32_envelope(orc, params):
+    """The Float32-typed restatement (oracle/ldsp_oracle.c -DORC_F32: what the reference computes for Float32 input) against the
+    Float64 one on the seeded batch: printed per column next to the HIP path's error (tests/parity.py, module text).  The HIP
+    path must lie INSIDE that envelope wherever the envelope is wider than the column's own floor — it does by one to three orders
+    of magnitude (no column of a statistic, energy, drift or current may come closer than a third of it)."""
+    n = 256
+    wf = ldsp.synth.hpge_batch(n, L, device="cuda", seed=101)
+    host = wf.cpu().numpy()
+    gpu = _run(wf, params)
+    ora = orc.dsp_icpc(host, params, nthreads=16)
+    env = orc.dsp_icpc(host, params, nthreads=16, f32=True)
+    lines, worst = parity.compare(gpu, ora, wf=host, params=params, orc=orc, env=env)
+    print("\n".join(lines))
+    assert worst <= parity.FLIP_FRAC, "\n".join(lines)
+    for c in ("tailmean", "tailsigma", "tailoffset", "blsigma", "e_10410", "e_535", "e_313", "e_trap", "e_cusp", "e_trap_max", "e_cusp_max", "qdrift", "lq"):
+        e_hip = np.nanmax(np.abs(np.asarray(gpu[c], dtype=np.float64) - ora[c]))
+        e_f32 = np.nanmax(np.abs(env[c] - ora[c]))
+        assert e_hip <= e_f32 / 3, (c, e_hip, e_f32)
+
+
+def test_reference_fake_waveform_properties(orc, params):
     """The smoke properties the reference asserts (test/test_dsp_icpc.jl:189-199) plus the
-    analytic consequences of its noiseless fixture."""
+    analytic consequences of its noiseless fixture; and the whole table against the oracle — the pile-up columns
+    too where the Float32 and the Float64 restatement agree with each other on this noise-free trace (tests/parity.py)."""
     wf = ldsp.synth.reference_hpge_waveform().float()[None].repeat(3, 1).cuda()
     g = _run(wf, params)
+    host = wf.cpu().numpy()
+    ora = orc.dsp_icpc(host, params, nthreads=2)
+    env = orc.dsp_icpc(host, params, nthreads=2, f32=True)
+    lines, rows = parity.compare_rows(g, ora, wf=host, params=params, orc=orc, env=env)
+    print("\n".join(l for l in lines if l.startswith("inTrace")))
+    assert rows == 0, "\n".join(lines)
     assert np.all(g["t0"] < g["t50"]) and np.all(g["t50"] < g["t90"]) and np.all(g["drift_time"] >= 0)
     for c in ("e_10410", "e_313", "e_trap", "e_cusp", "e_zac"):
         assert np.all(np.isfinite(g[c]))
@@ -94,16 +121,16 @@ def test_other_lengths_and_filter_parameters(orc):
     wf = ldsp.synth.hpge_batch(64, 4096, device="cuda")
     gpu = _run(wf, p1)
     ora = orc.dsp_icpc(wf.cpu().numpy(), p1, nthreads=8)
-    lines, worst = parity.compare(gpu, ora)
-    assert worst <= 0.02, "\n".join(lines)
+    lines, rows = parity.compare_rows(gpu, ora)
+    assert rows <= 1, "\n".join(lines)
     pf = {"trap": {"rt": 8 * ldsp.us, "ft": 3 * ldsp.us}, "cusp": {"rt": 4 * ldsp.us, "ft": 2 * ldsp.us},
           "zac": {"rt": 6 * ldsp.us, "ft": 1.5 * ldsp.us}, "sg": {"wl": 180 * ldsp.ns}}
     p2 = ldsp.lower_icpc(cfg, 450 * ldsp.us, pf, L, 0.0, 16.0)
     wf = ldsp.synth.hpge_batch(64, L, device="cuda", seed=7)
     gpu = _run(wf, p2)
     ora = orc.dsp_icpc(wf.cpu().numpy(), p2, nthreads=8)
-    lines, worst = parity.compare(gpu, ora)
-    assert worst <= 0.02, "\n".join(lines)
+    lines, rows = parity.compare_rows(gpu, ora)
+    assert rows <= 1, "\n".join(lines)
 
 
 def test_pz_trap_subchain(orc, params):
@@ -137,8 +164,8 @@ def test_trace_lengths_that_do_not_fill_the_tile(orc, Lx):
     wf = ldsp.synth.hpge_batch(48, 8192, device="cuda", seed=13)[:, :Lx].contiguous()
     gpu = _run(wf, p)
     ora = orc.dsp_icpc(wf.cpu().numpy(), p, nthreads=8)
-    lines, worst = parity.compare(gpu, ora)
-    assert worst <= 0.03, "\n".join(lines)
+    lines, rows = parity.compare_rows(gpu, ora)
+    assert rows <= 1, "\n".join(lines)
 
 
 def test_two_launch_form_equals_fused(params, orc):
@@ -171,8 +198,8 @@ def test_long_traces_16384(orc):
     wf = ldsp.synth.hpge_batch(32, Lx, device="cuda", seed=19)
     gpu = _run(wf, p)
     ora = orc.dsp_icpc(wf.cpu().numpy(), p, nthreads=8)
-    lines, worst = parity.compare(gpu, ora)
-    assert worst <= 0.04, "\n".join(lines)
+    lines, rows = parity.compare_rows(gpu, ora)
+    assert rows <= 1, "\n".join(lines)
 
 
 def test_threshold_crossings_with_spikes_before_the_pulse(orc, params):
