@@ -36,7 +36,7 @@
 #endif
 
 namespace ldsp {
-extern int g_dbg_lds_pad;   // option "dbg_lds_pad" (icpc_lean.hip)
+extern int g_dbg_lds_pad;   // option "dbg_lds_pad" (defined in icpc_lean.hip)
 namespace lean3 {
 
 typedef __attribute__((address_space(3))) float lds_float;
@@ -437,7 +437,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     const float mx = fold_partials<NW>(S.wred + 3 * NW, -INFINITY, [](float a, float b) { return vmax(a, b); });
     const float mn = fold_partials<NW>(S.wred + 4 * NW, INFINITY, [](float a, float b) { return vmin(a, b); });
     delta = s * (float)P.bl.inv_n;
-    blmean = fmaf(s, (float)P.bl.inv_n, pv_bl);   // (the statement of pz_trap_lean_kernel: config 2 reports the same bits)
+    blmean = fmaf(s, (float)P.bl.inv_n, pv_bl);   // (the statement of pz_trap_lean_kernel, icpc_lean.hip: config 2 reports the same bits)
     if (ext_bl) { blmean = ext_bl[blockIdx.x] * ext_bl_scale; delta = blmean - pv_bl; }   // windowed traces of dsp_icpc_compressed (dsp_icpc.jl:353)
     raw_max = mx; raw_min = mn;
   }
@@ -1601,201 +1601,6 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// BASELINE config 2: blmean -> shift -> InvCR -> Trap(10 us, 4 us) -> maximum (reference src/dsp_icpc.jl:102-105,119-120,
-// 147-148).  The statements of icpc_lean3_kernel's round 1 and of its sweep for that trapezoid, nothing else: blmean and e_10410
-// come out bit-identical to the fused chain's columns (tests/test_baseline_sizes_gpu.py).  ONE exchange of per-wave partials
-// (baseline sum + prefix scans of the pivoted trace) and three barriers in all; one trace-sized LDS array (T): four workgroups
-// per CU.  U16: the traces are uint16 ADC counts, converted as they are loaded.
-template <int NT, bool U16>
-__global__ void __launch_bounds__(NT, 8)
-pz_trap_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, float* __restrict__ o_blmean, float* __restrict__ o_e10410) {
-  constexpr int NW = NT / 64, Lp = NT * SP, L = Lp;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const IcpcDev& P = *Pp;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* X = reinterpret_cast<float*>(smem_raw);           // [Lp + 64] T, + 2 NT floats of slack (the row pair that holds the end of
-  float* part = X + Lp + 64 + 2 * NT;                      // the output range reads past T, masked)                      [2][R*NW]
-  float* wred = part + 2 * R * NW;                         // [2][NW]: s1 partials, trapezoid maxima
-  float* tend = wred + 2 * NW;                             // [2]: T[L] without the delta terms, hi + lo
-  float* tabs = tend + 2;                                  // [3][R*NW]: the row tables (hi, lo, b), [wave][r]
-  const float* w = wf + (size_t)blockIdx.x * (size_t)L;
-  const uint16_t* w16 = reinterpret_cast<const uint16_t*>(wf) + (size_t)blockIdx.x * (size_t)L;
-  f4 x[R];
-  if constexpr (U16) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const uint2 q = *reinterpret_cast<const uint2*>(w16 + 4 * (tid + NT * r));
-      x[r] = (f4){(float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16)};
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
-  }
-  asm volatile("; LDSP_PHASE 1");
-  const float pv_bl = U16 ? (float)w16[P.bl.from] : w[P.bl.from];
-  const uint32_t cls_bl = P.rowcls[0][wave];
-  if (tid >= 1 && tid < 64) X[Lp + tid] = 0.f;
-  float ex1[R], ex2[R];
-  {   // round 1 of icpc_lean3_kernel: baseline sum and the prefix scans of x' = raw - pv
-    f2 a1 = splat(0.f);
-    const f2 pv = splat(pv_bl);
-    float t[R], q2[R], i1[R], i2[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      x[r].xy -= pv; x[r].zw -= pv;
-      const float c0 = x[r].x, c1 = c0 + x[r].y, c2 = c1 + x[r].z, c3 = c2 + x[r].w;
-      t[r] = c3; i1[r] = c3;
-      q2[r] = (c0 + c1) + (c2 + c3);
-      if ((cls_bl >> r) & 1u) continue;
-      f2 d0 = x[r].xy, d1 = x[r].zw;
-      if (!((cls_bl >> (4 + r)) & 1u)) {
-        const int i0 = 4 * (tid + NT * r), lo = P.bl.from - i0, hi = P.bl.until - i0;
-        d0.x = (lo <= 0 && hi >= 0) ? d0.x : 0.f; d0.y = (lo <= 1 && hi >= 1) ? d0.y : 0.f;
-        d1.x = (lo <= 2 && hi >= 2) ? d1.x : 0.f; d1.y = (lo <= 3 && hi >= 3) ? d1.y : 0.f;
-      }
-      a1 += d0 + d1;
-    }
-    float s1 = hsum(a1);
-    LDSP_DPP_GROUP5("v_add_f32_dpp", s1, "v_add_f32_dpp", i1[0], "v_add_f32_dpp", i1[1], "v_add_f32_dpp", i1[2], "v_add_f32_dpp", i1[3]);
-#pragma unroll
-    for (int r = 0; r < R; ++r) { ex1[r] = i1[r] - t[r]; i2[r] = fmaf(4.f, ex1[r], q2[r]); ex2[r] = i2[r]; }
-    LDSP_DPP_GROUP4("v_add_f32_dpp", i2[0], "v_add_f32_dpp", i2[1], "v_add_f32_dpp", i2[2], "v_add_f32_dpp", i2[3]);
-#pragma unroll
-    for (int r = 0; r < R; ++r) ex2[r] = i2[r] - ex2[r];
-    if (lane == 63) {
-      wred[wave] = s1;
-      *reinterpret_cast<f4*>(&part[4 * wave]) = (f4){i1[0], i1[1], i1[2], i1[3]};
-      *reinterpret_cast<f4*>(&part[R * NW + 4 * wave]) = (f4){i2[0], i2[1], i2[2], i2[3]};
-    }
-  }
-  asm volatile("; LDSP_PHASE 2");
-  __syncthreads();
-  // (here ONE wave makes the row tables and the others wait at a barrier: this kernel has few instructions per wave, and the
-  // ~120 of the three double-precision scans in every wave cost more than the barrier — 146 M against 1xx M waveforms/s)
-  if (wave == 0) {
-    float tab_hi, tab_lo, tab_b;
-    const int jr = lane / NW, jw = lane - jr * NW;
-    const bool in = lane < R * NW;
-    const double sv = in ? (double)part[4 * jw + jr] : 0.0, qv = in ? (double)part[R * NW + 4 * jw + jr] : 0.0, jv = sv * (double)lane;
-    const double c1i = wave_incl_scan_sum_f64(sv), qi = wave_incl_scan_sum_f64(qv), ji = wave_incl_scan_sum_f64(jv);
-    const double c1x = c1i - sv;
-    const double c2x = (qi - qv) + 256.0 * ((double)(lane - 1) * c1x - (ji - jv));
-    const double c2i = qi + 256.0 * ((double)lane * c1i - ji);
-    const double A = fma(P.pz_c64, c2x, c1x);
-    tab_hi = (float)A; tab_lo = (float)(A - (double)tab_hi); tab_b = (float)(P.pz_c64 * c1x);
-    if (in) { tabs[4 * jw + jr] = tab_hi; tabs[R * NW + 4 * jw + jr] = tab_lo; tabs[2 * R * NW + 4 * jw + jr] = tab_b; }
-    const double At = fma(P.pz_c64, readlane_d(c2i, R * NW - 1), readlane_d(c1i, R * NW - 1));
-    if (lane == 0) { const float ah = (float)At; tend[0] = ah; tend[1] = (float)(At - (double)ah); }
-  }
-  float s = 0.f;
-#pragma unroll
-  for (int ww = 0; ww < NW; ++ww) s += wred[ww];
-  const float delta = s * (float)P.bl.inv_n;
-  const float blmean = pv_bl + delta;
-  __syncthreads();
-  {
-    const f4 h4 = *reinterpret_cast<const f4*>(&tabs[4 * wave]), l4 = *reinterpret_cast<const f4*>(&tabs[R * NW + 4 * wave]),
-             b4 = *reinterpret_cast<const f4*>(&tabs[2 * R * NW + 4 * wave]);
-    const float hw[R] = {h4.x, h4.y, h4.z, h4.w}, lw[R] = {l4.x, l4.y, l4.z, l4.w}, bw[R] = {b4.x, b4.y, b4.z, b4.w};
-    const float c = P.pz_c, cd = c * delta, hc = 0.5f * c;
-    const float n0 = (float)(4 * lane);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i0 = 4 * (tid + NT * r);
-      const float fi = (float)i0;
-      const float Hr = hw[r], Lr = lw[r], Br = bw[r];
-      const float c0 = x[r].x, c1 = c0 + x[r].y, c2 = c1 + x[r].z, c3 = c2 + x[r].w;
-      const f4 xs = (f4){x[r].x - delta, x[r].y - delta, x[r].z - delta, x[r].w - delta};
-      {
-        const float ky = fmaf(c, ex1[r], Br) - cd * (fi + 1.f);
-        x[r].x = xs.x + fmaf(c, c0, ky);
-        x[r].y = xs.y + fmaf(c, c1, ky - cd);
-        x[r].z = xs.z + fmaf(c, c2, ky - 2.f * cd);
-        x[r].w = xs.w + fmaf(c, c3, ky - 3.f * cd);
-      }
-      {
-        const float in0 = fmaf(-delta, fi * fmaf(hc, fi + 1.f, 1.f), fmaf(c, ex2[r], fmaf(n0, Br, ex1[r])));
-        const float in1 = in0 + x[r].x, in2 = in1 + x[r].y, in3 = in2 + x[r].z;
-        const float H = Hr, Lo = Lr;
-        *reinterpret_cast<f4*>(&X[i0]) = (f4){H + (Lo + in0), H + (Lo + in1), H + (Lo + in2), H + (Lo + in3)};
-      }
-    }
-    if (tid == 0) X[Lp] = tend[0] + (tend[1] - delta * ((float)L * fmaf(hc, (float)(L + 1), 1.f)));   // T[L]
-  }
-  asm volatile("; LDSP_PHASE 3");
-  __syncthreads();
-  float mx0 = -INFINITY;
-  {
-    const TrapDev f0 = P.fixed[0];
-    const float* tb = &X[tid];
-    const float *f0a = tb + f0.n1, *f0b = tb + f0.n1 + f0.g, *f0c = tb + f0.flen;
-    const f2 rr0 = splat(f0.rr);
-    const int n0 = L - f0.flen + 1;
-    auto rd2 = [&](const float* p, int m) { return mk2(p[NT * m], p[NT * (m + 1)]); };
-    auto pair = [&](auto mtag, bool whole) {
-      constexpr int m = decltype(mtag)::value;
-      const f2 Tk = rd2(tb, m), a0 = rd2(f0a, m), b0 = rd2(f0b, m), c0_ = rd2(f0c, m);
-      const f2 o0 = fma2(c0_ - b0, rr0, Tk - a0);
-      if (whole) mx0 = vmax3(mx0, o0.x, o0.y);
-      else mx0 = vmax3(mx0, tid + NT * m < n0 ? o0.x : -INFINITY, tid + NT * (m + 1) < n0 ? o0.y : -INFINITY);
-    };
-    static_assert(SP == 16, "eight row pairs");
-#define LDSP_PAIR(k) std::integral_constant<int, 2 * (k)>{}
-    const int np = n0 / (2 * NT);   // pairs wholly inside the output range (block-uniform)
-    switch (np) {
-      case 8: pair(LDSP_PAIR(7), true); [[fallthrough]];
-      case 7: pair(LDSP_PAIR(6), true); [[fallthrough]];
-      case 6: pair(LDSP_PAIR(5), true); [[fallthrough]];
-      case 5: pair(LDSP_PAIR(4), true); [[fallthrough]];
-      case 4: pair(LDSP_PAIR(3), true); [[fallthrough]];
-      case 3: pair(LDSP_PAIR(2), true); [[fallthrough]];
-      case 2: pair(LDSP_PAIR(1), true); [[fallthrough]];
-      case 1: pair(LDSP_PAIR(0), true); [[fallthrough]];
-      default: break;
-    }
-    if (n0 > 2 * NT * np) {
-      switch (np) {
-        case 0: pair(LDSP_PAIR(0), false); break;
-        case 1: pair(LDSP_PAIR(1), false); break;
-        case 2: pair(LDSP_PAIR(2), false); break;
-        case 3: pair(LDSP_PAIR(3), false); break;
-        case 4: pair(LDSP_PAIR(4), false); break;
-        case 5: pair(LDSP_PAIR(5), false); break;
-        case 6: pair(LDSP_PAIR(6), false); break;
-        default: pair(LDSP_PAIR(7), false); break;
-      }
-    }
-#undef LDSP_PAIR
-    mx0 *= f0.inv1;
-  }
-  asm volatile("; LDSP_PHASE 4");
-  LDSP_DPP_GROUP1("v_max_f32_dpp", mx0);
-  if (lane == 63) wred[NW + wave] = mx0;
-  __syncthreads();
-  if (tid == 0) {
-    float m = wred[NW];
-    for (int ww = 1; ww < NW; ++ww) m = vmax(m, wred[NW + ww]);
-    o_blmean[blockIdx.x] = blmean;
-    o_e10410[blockIdx.x] = m;
-  }
-}
-
-template <int NT, bool U16>
-static hipError_t launch_pz_tu(const float* wf, int64_t n, const IcpcDev* dP, float* a, float* b, hipStream_t st) {
-  constexpr int NW = NT / 64;
-  const size_t smem = (size_t)(NT * SP + 64 + 2 * NT + 2 * R * NW + 2 * NW + 2 + 3 * R * NW) * 4 + 16;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pz_trap_lean3_kernel<NT, U16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((pz_trap_lean3_kernel<NT, U16>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, a, b);
-  return hipGetLastError();
-}
-template <int NT>
-static hipError_t launch_pz_t(const float* wf, int64_t n, bool u16, const IcpcDev* dP, float* a, float* b, hipStream_t st) {
-  return u16 ? launch_pz_tu<NT, true>(wf, n, dP, a, b, st) : launch_pz_tu<NT, false>(wf, n, dP, a, b, st);
-}
-
 template <int NT, int M, bool SEP>
 static hipError_t launch_t(const float* wf, int64_t n, const IcpcDev* dP, const IcpcOutDev& out, const float* ext_bl, float ext_bl_scale,
                            int Lf, hipStream_t st) {
@@ -1816,18 +1621,6 @@ size_t icpc_lean3_smem_bytes(int NT, int Lf) {
     case 256: return lean3::Smem<256>::bytes(lean3::cz_pad_floats(Lf));
     case 512: return lean3::Smem<512>::bytes(lean3::cz_pad_floats(Lf));
     default: return (size_t)-1;
-  }
-}
-
-hipError_t launch_pz_trap_lean3(const float* wf, int64_t n, int NT, bool u16, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st) {
-  switch (NT) {
-#ifndef LDSP_DEV_512
-    case 64: return lean3::launch_pz_t<64>(wf, n, u16, dP, blmean, e10410, st);
-    case 128: return lean3::launch_pz_t<128>(wf, n, u16, dP, blmean, e10410, st);
-    case 256: return lean3::launch_pz_t<256>(wf, n, u16, dP, blmean, e10410, st);
-#endif
-    case 512: return lean3::launch_pz_t<512>(wf, n, u16, dP, blmean, e10410, st);
-    default: return hipErrorInvalidValue;
   }
 }
 

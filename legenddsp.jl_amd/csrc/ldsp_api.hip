@@ -19,13 +19,9 @@ namespace ldsp {
 hipError_t launch_icpc(const float* wf, int64_t n, int NT, int R, bool full, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
                        const float* ext_bl, float ext_bl_scale, bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid,
                        int* stages);
-hipError_t launch_icpc_lean(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, const IcpcDev* dP, const IcpcOutDev& out,
-                            const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st);
-size_t icpc_lean_smem_bytes(int NT, int Lf);
 hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, const IcpcDev* dP, const IcpcOutDev& out,
                              const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st);
 size_t icpc_lean3_smem_bytes(int NT, int Lf);
-hipError_t launch_pz_trap_lean3(const float* wf, int64_t n, int NT, bool u16, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 extern int g_dbg_lds_pad;
 hipError_t launch_pz_trap_lean(const float* wf, int64_t n, int NT, bool u16, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
 hipError_t launch_pz_trap(const float* wf, int64_t n, int NT, bool full, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
@@ -152,9 +148,6 @@ int ldsp_ctx_set_option(ldsp_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "sipm_generic")) { c->sipm_generic = value != 0; return LDSP_OK; }
   if (!strcmp(key, "dbg_stop")) { c->dbg_stop = (int)value; c->icpc_valid = false; return LDSP_OK; }
   if (!strcmp(key, "dbg_lds_pad")) { ldsp::g_dbg_lds_pad = (int)value; return LDSP_OK; }
-  if (!strcmp(key, "icpc_lean2")) { c->icpc_lean2 = value != 0; return LDSP_OK; }
-  if (!strcmp(key, "icpc_lean3")) { c->icpc_lean3 = value != 0; return LDSP_OK; }
-  if (!strcmp(key, "pz_lean3")) { c->pz_lean3 = value != 0; return LDSP_OK; }
   if (!strcmp(key, "icpc_generic")) { c->icpc_generic = value != 0; return LDSP_OK; }
   if (!strcmp(key, "icpc_r2")) { c->icpc_r2 = value != 0; c->icpc_valid = false; return LDSP_OK; }
   if (!strcmp(key, "dbg_stamps")) { c->dbg_stamps = reinterpret_cast<long long*>((uintptr_t)value); c->icpc_valid = false; return LDSP_OK; }
@@ -436,30 +429,23 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, int r2, Ic
   return LDSP_OK;
 }
 
-// the lean kernels (icpc_lean.hip) cover the standard geometry: the trace fills the tile, CUSP and ZAC in closed form (sharing
-// their geometry: one pass; optimised separately: one pass each inside the same launch), the inverted t0 uses the same trapezoid, tx_mintot <= 2 samples, Savitzky-Golay windows of at most 13 taps,
-// two traces per CU.  ldsp_icpc_run and ldsp_icpc_pz_trap_run decide alike, so that config 2's columns stay bit-identical
-// to the fused chain's.
+// The lean kernels (icpc_lean3.hip: the fused chain; icpc_lean.hip: config 2's sub-chain) cover the standard geometry: the trace
+// fills the tile (L = 16 NT, NT <= 512), CUSP and ZAC in closed form (sharing their geometry: one pass; optimised separately:
+// one pass each inside the same launch), the inverted t0 uses the same trapezoid, tx_mintot <= 2 samples, Savitzky-Golay windows
+// of at most 13 taps, the chain of ZAC shifts with the parabola's last tap folded in exists (icpc_dev.hpp: zf_*), and the
+// eps * T term of the filters' last tap, which icpc_lean3 drops, is far below the columns' resolution: |w_last| * eps * rail * L
+// < 1e-2 on a trace that sits at the rail, a hundredth of that on a real one (dsp_icpc sets the filters' tau to 1e7 us,
+// src/dsp_icpc.jl:98: 1.4e-3 for a 16-bit rail and 8192 samples).  ldsp_icpc_run and ldsp_icpc_pz_trap_run decide alike.
 static bool icpc_lean_applies(const ldsp_ctx* c) {
   const IcpcDev& H = c->icpc_host;
   const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
-  return !c->icpc_generic && !c->two_kernel && (c->dbg_stop == 0 || c->dbg_stop >= 100) && H.R == 4 && H.L == 16 * H.NT && H.cusp_mode == 1 &&
-         H.t0inv_same && H.tx_mintot <= 2 && sg_max <= 13 &&
-         icpc_lean_smem_bytes(H.NT, std::max(H.cusp.Lf, H.zac.Lf)) <= 80640;   // two traces per CU (160 KiB LDS, 1280-byte granules)
-}
-
-// icpc_lean3.hip (one trace-sized LDS array, three workgroups per CU) takes what the round-2 lean kernel takes, for tiles of up to
-// 512 threads, where the last tap's eps * T term it drops is far below the columns' resolution (|w_last| * eps * rail * L < 1e-2 on a
-// trace that sits at the rail, a hundredth of that on a real one;
-// dsp_icpc sets the filters' tau to 1e7 us, src/dsp_icpc.jl:98: 1.4e-3 for a 16-bit rail and 8192 samples).  Option "icpc_lean2"
-// selects the round-2 kernel (comparator).
-static bool icpc_lean3_applies(const ldsp_ctx* c) {
-  const IcpcDev& H = c->icpc_host;
-  if (!c->icpc_lean3 || c->icpc_lean2 || !icpc_lean_applies(c) || H.NT > 512) return false;
+  if (c->icpc_generic || c->two_kernel || !(c->dbg_stop == 0 || c->dbg_stop >= 100) || H.R != 4 || H.L != 16 * H.NT || H.NT > 512 ||
+      H.cusp_mode != 1 || !H.t0inv_same || H.tx_mintot > 2 || sg_max > 13)
+    return false;
   const double rail = std::max(std::fabs((double)H.sat_high), std::fabs((double)H.sat_low)) * (double)H.L;
   const double drop = std::max(std::fabs((double)H.cusp.w_last) * H.cusp.eps, std::fabs((double)H.zac.w_last) * H.zac.eps) * rail;
-  if (H.cz_shared && H.zac.zf_n <= 0) return false;   // (the chain of ZAC shifts with the last tap folded in: icpc_dev.hpp)
-  return drop < 1e-2 && icpc_lean3_smem_bytes(H.NT, std::max(H.cusp.Lf, H.zac.Lf)) <= 80640;
+  if (H.cz_shared && H.zac.zf_n <= 0) return false;
+  return drop < 1e-2 && icpc_lean3_smem_bytes(H.NT, std::max(H.cusp.Lf, H.zac.Lf)) <= 80640;   // (<= 53 760: three workgroups per CU)
 }
 
 static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p, int in_u16 = 0) {
@@ -526,19 +512,12 @@ int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_
   }
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   int stages = 1;
-  // the lean kernel (icpc_lean.hip) covers the standard geometry; everything else — and option "icpc_generic" — runs icpc_kernel
+  // the lean kernel (icpc_lean3.hip) covers the standard geometry; everything else — and option "icpc_generic" — runs icpc_kernel
   const IcpcDev& H = c->icpc_host;
   const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
-  const bool lean_ok = icpc_lean_applies(c) && !main_only;
-  if (lean_ok && icpc_lean3_applies(c)) {
+  if (icpc_lean_applies(c) && !main_only) {
     HIP_TRY(launch_icpc_lean3(wf, n, H.NT, sg_max, H.cz_shared != 0, c->d_icpc, od, ext_bl, ext_bl_scale, std::max(H.cusp.Lf, H.zac.Lf), c->stream));
     c->last_kernel = "lean3::icpc_lean3_kernel";
-    if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
-    return LDSP_OK;
-  }
-  if (lean_ok) {
-    HIP_TRY(launch_icpc_lean(wf, n, H.NT, sg_max, H.cz_shared != 0, c->d_icpc, od, ext_bl, ext_bl_scale, std::max(H.cusp.Lf, H.zac.Lf), c->stream));
-    c->last_kernel = "lean::icpc_lean_kernel";
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
     return LDSP_OK;
   }
@@ -562,13 +541,7 @@ static int pz_trap_run_impl(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_
   if (rc) return rc;
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   const int nt_pz = c->icpc_host.R == 2 ? 512 : c->icpc_host.NT;   // pz_trap_kernel keeps 16 samples per thread
-  // (pz_trap_lean3_kernel — the round-3 kernel's single exchange of partial sums, three barriers instead of six — is available
-  // through option "pz_lean3" and measured SLOWER, 146 M against 170 M waveforms/s: this sub-chain is bound by its ~400
-  // instructions per wave, and the merged prefix scans cost 100 more)
-  if (c->pz_lean3 && icpc_lean3_applies(c)) {
-    HIP_TRY(launch_pz_trap_lean3(wf, n, c->icpc_host.NT, in_u16, c->d_icpc, blmean, e_10410, c->stream));
-    c->last_kernel = "lean3::pz_trap_lean3_kernel";
-  } else if (icpc_lean_applies(c)) {
+  if (icpc_lean_applies(c)) {
     HIP_TRY(launch_pz_trap_lean(wf, n, c->icpc_host.NT, in_u16, c->d_icpc, blmean, e_10410, c->stream));
     c->last_kernel = "lean::pz_trap_lean_kernel";
   } else {

@@ -58,9 +58,6 @@ struct ldsp_ctx {
   int two_kernel = 0;   // option "two_kernel": never fuse the CUSP/ZAC stage into icpc_kernel
   int dbg_stop = 0;
   int icpc_generic = 0;  // option "icpc_generic": always icpc_kernel, never the lean kernel (comparator)
-  int icpc_lean3 = 1;   // option "icpc_lean3" (default on): icpc_lean3.hip, one LDS array, three workgroups per CU; 0 = the round-2 lean kernel
-  int pz_lean3 = 0;     // option "pz_lean3": config 2's sub-chain by pz_trap_lean3_kernel (comparator; slower than pz_trap_lean_kernel)
-  int icpc_lean2 = 0;   // option "icpc_lean2": the round-2 lean kernel (two LDS arrays) instead of icpc_lean3 (comparator)
   int icpc_r2 = 0;      // option "icpc_r2": 4097..8192-sample traces on 1024 threads x 8 samples (8 waves per SIMD) instead of 512 x 16
   long long* dbg_stamps = nullptr;   // option "dbg_stamps": device buffer of a diagnostic (LDSP_STAMPS) build
   int multi_serial = 0;          // option "multi_serial": MultiIntersect by the reference's one-lane walk (comparator of the wave-parallel search)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/dev_build.sh TAG [extra hipcc flags] — development library build/dev/libldsp_TAG.so: icpc_lean3.hip compiled with
 # -DLDSP_DEV_512 (512-thread instantiations only, ~20 s) plus the given flags, linked with cached -DLDSP_DEV_512 objects of
-# icpc_lean.hip / icpc_kernel.hip (rebuilt when their sources are newer) and the production objects of the other translation
+# icpc_lean.hip (config 2) / icpc_kernel.hip (rebuilt when their sources are newer) and the production objects of the other translation
 # units.  Select it with LDSP_HIP_LIB=build/dev/libldsp_TAG.so (tools/ and tests honour it).
 set -e
 cd "$(dirname "$0")/.."

@@ -1,4 +1,4 @@
-"""Throughput of icpc_lean_kernel against resident workgroups per CU (option dbg_lds_pad inflates the LDS request).
+"""Throughput of icpc_lean3_kernel against resident workgroups per CU (option dbg_lds_pad inflates the LDS request).
 L = 8192 (512 threads: 1 or 2 workgroups = 2 / 4 waves per SIMD) and L = 4096 at 32 ns (256 threads: 1..4 workgroups =
 1..4 waves per SIMD, same VGPR count).  usage: python tools/occ_probe.py"""
 import sys, os
@@ -11,9 +11,8 @@ for L, dt, n, base in ((8192, 16.0, 65536, 80640),):
     p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, L, 0.0, dt)
     wf = ldsp.synth.hpge_batch(n, L, device="cuda")
     out = torch.empty((n, 48), dtype=torch.float32, device="cuda")
-    for lean2 in (0, 1):
-      ctx.set_option("icpc_lean3", 1 - lean2)
-      for pad in ((0, 10000, 30000, 60000) if not lean2 else (0, 60000)):
+    for generic in (0,):
+      for pad in (0, 10000, 60000):   # three / two / one workgroup(s) per CU
         ctx.set_option("dbg_lds_pad", pad)
         ts = []
         for _ in range(5):

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 STOPS="1 2 3 4 5 6 7 9 11 13 14 15 16 17 18 19 20 21 22 0"
 for k in $STOPS; do
   stop=$((100 + k)); [ $k = 0 ] && stop=0
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT -d $O/s$k -o p --output-format csv -- python3 $R/tools/prof_small.py 16384 icpc_lean3=1 dbg_stop=$stop > $O/s$k.log 2>&1 || true
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT -d $O/s$k -o p --output-format csv -- python3 $R/tools/prof_small.py 16384 dbg_stop=$stop > $O/s$k.log 2>&1 || true
 done
 python3 - <<PY
 import csv, collections, glob
