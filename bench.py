@@ -163,19 +163,31 @@ def timed(env, args, step, finish=lambda: None):
     return env.max_over_ranks(time.perf_counter() - t0)
 
 
-def roofline(achieved_gbs, kernel, kernel_ms, bytes_per_trace, traffic):
+# Compute-issue ceilings of the full dsp_icpc chain at L = 8192 (waveforms/s per GPU):
+#   "algorithmic": ~130 flop per sample at 0.5 plain VALU instructions per SIMD cycle, perfectly packed (round 2's estimate);
+#   "instruction_stream": the VALU instructions icpc_lean3_kernel actually issues (3 430 per wave of 16 samples per lane,
+#   profiles/r03_phase_counters.txt) at the measured mix of 2- and 4-cycle instructions (~2.5 cycles each) on 1 024 SIMDs at 2.4 GHz.
+ISSUE_CEILING_ICPC = {"algorithmic": 65.0e6, "instruction_stream": 35.8e6}
+
+
+def roofline(achieved_gbs, kernel, kernel_ms, bytes_per_trace, traffic, issue_of=None):
     r = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
          "traffic": None, "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_trace": bytes_per_trace}
     if traffic:
         r["traffic"] = traffic["bytes"]
         r["traffic_source"] = traffic["source"]
+    if issue_of is not None:   # the second ceiling of this chain: instruction issue (waveforms/s of ONE GPU against it)
+        r["issue"] = {"unit": "waveforms/s", "achieved": issue_of,
+                      "ceiling_algorithmic": ISSUE_CEILING_ICPC["algorithmic"], "frac_algorithmic": issue_of / ISSUE_CEILING_ICPC["algorithmic"],
+                      "ceiling_instruction_stream": ISSUE_CEILING_ICPC["instruction_stream"],
+                      "frac_instruction_stream": issue_of / ISSUE_CEILING_ICPC["instruction_stream"]}
     return r
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # dsp_icpc (config 3 / 4) and the pole-zero + trapezoid sub-chain (config 2)
 
-def bench_icpc(env, args, n, L, workload, wf=None):
+def bench_icpc(env, args, n, L, workload, wf=None, pars_filter=None, label=None):
     torch = env.torch
     from legenddsp_jl_amd import dist as ldist
     world, rank, dev = env.world, env.rank, env.dev
@@ -184,7 +196,7 @@ def bench_icpc(env, args, n, L, workload, wf=None):
         import legenddsp_jl_amd as ldsp
         dt = 16.0 * (8192 / L) if L < 8192 else 16.0  # 4096-sample plumbing config needs 32 ns
         cfg = ldsp.reference_test_icpc_config() if L >= 8192 else ldsp.plumbing_icpc_config_4096()
-        params = ldsp.lower_icpc(cfg, 500 * ldsp.us, {}, L, 0.0, dt)
+        params = ldsp.lower_icpc(cfg, 500 * ldsp.us, pars_filter or {}, L, 0.0, dt)
         if wf is None:   # synthetic input, generated directly in HBM (excluded from timing)
             wf = torch.empty((n, L), dtype=torch.float32, device=dev)
             ldsp.synth.hpge_batch(n, L, device=dev, out=wf, first_trace=rank * n)
@@ -290,39 +302,66 @@ def bench_icpc(env, args, n, L, workload, wf=None):
                        "traces_per_gpu": n, "samples": L, "dt_ns": dt,
                        "dsp_config": "reference test/test_dsp_icpc.jl:50-161", "tau_us": 500,
                        "gather": "rccl gather of [n,48] f32 to rank 0, overlapped with the next batch's kernel (double-buffered)" if pipe else "none"},
-            "roofline": roofline(achieved, dom_kernel, dom_ms, bytes_per_trace, measured_traffic(dom_kernel, n, L)),
+            "roofline": roofline(achieved, dom_kernel, dom_ms, bytes_per_trace, measured_traffic(dom_kernel, n, L),
+                                 issue_of=(n / (dom_ms * 1e-3)) if (workload == "icpc" and L == 8192) else None),
         }
+        if label:
+            res["config"]["workload"] = label
         if workload == "icpc":
             res["roofline"]["launches"] = f"1 ({dom_kernel}, CUSP/ZAC fused)" if fused else "2 (icpc_kernel + icpc_cz_kernel)"
             if not fused:
                 res["roofline"]["chain"] = {  # both kernels together against the path's algorithmic bytes
                     "kernels_ms": {"icpc_kernel": k1, "icpc_cz_kernel": k2}, "algorithmic_bytes_per_trace": chain_bytes,
                     "achieved": n * chain_bytes / (kms * 1e-3) / 1e9, "frac": n * chain_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if world == 1 and args.cpu_sample > 0 and workload == "icpc":
+        if world == 1 and args.cpu_sample > 0 and workload == "icpc" and label is None:
             res["cpu_baseline"] = cpu_baseline(args, wf, params, n)
     return res, wf
 
 
+def cpu_model():
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if line.startswith("Model name"):
+                return line.split(":", 1)[1].strip()
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, wf, params, n):
+    """the CPU restatement structured like the reference (one materialised pass per broadcast, float64), CUSP / ZAC by
+    direct convolution AND by FFT (upstream's ConvolutionFilter has both; which one dsp_icpc takes is not visible in the
+    reference), each on all host cores (one OpenMP worker per core over disjoint trace ranges) and on ONE core — the reference's
+    own execution model is single-threaded.  `value` = the faster all-core form."""
     from oracle import oracle as orc  # checker / CPU baseline only
     orc.build()
     m = min(args.cpu_sample, n)
     host = wf[:m].cpu().numpy()
     cores = min(os.cpu_count() or 1, 16)
-    orc.dsp_icpc(host[:cores], params, nthreads=cores)  # warm-up (thread pool, LSQ bases)
-    t1 = time.perf_counter()
-    orc.dsp_icpc(host, params, nthreads=cores)
-    cpu_t = time.perf_counter() - t1
-    # the reference itself is single-threaded: the same restatement on one core, smaller sample
     m1 = min(2048, m)
-    t2 = time.perf_counter()
-    orc.dsp_icpc(host[:m1], params, nthreads=1)
-    cpu_t1 = time.perf_counter() - t2
+    legs = {}
+    for form, fft in (("direct", False), ("fft", True)):
+        orc.set_fir_mode(fft)
+        try:
+            orc.dsp_icpc(host[:cores], params, nthreads=cores)  # warm-up (thread pool, LSQ bases)
+            t1 = time.perf_counter()
+            orc.dsp_icpc(host, params, nthreads=cores)
+            t_all = time.perf_counter() - t1
+            t2 = time.perf_counter()
+            orc.dsp_icpc(host[:m1], params, nthreads=1)
+            t_one = time.perf_counter() - t2
+        finally:
+            orc.set_fir_mode(False)
+        legs[form] = {"all_cores": {"value": m / t_all, "unit": "waveforms/s", "cores": cores, "sample": f"first {m} traces"},
+                      "single_thread": {"value": m1 / t_one, "unit": "waveforms/s", "cores": 1, "sample": f"first {m1} traces"}}
+    best = max(legs, key=lambda k: legs[k]["all_cores"]["value"])
     return {
-        "value": m / cpu_t, "unit": "waveforms/s", "cores": cores, "kind": "port",
-        "single_thread": {"value": m1 / cpu_t1, "unit": "waveforms/s", "cores": 1, "sample": f"first {m1} traces"},
-        "sample": f"first {m} traces of the same batch, float64 CPU restatement (oracle/ldsp_oracle.c), "
-                  f"OpenMP over traces, direct-form CUSP/ZAC; proxy for the single-threaded Julia reference",
+        "value": legs[best]["all_cores"]["value"], "unit": "waveforms/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+        "cusp_zac_form": best, "forms": legs,
+        "single_thread": legs[best]["single_thread"],
+        "sample": f"first {m} traces of the same batch (one core: first {m1}), float64 CPU restatement (oracle/ldsp_oracle.c) structured like the "
+                  f"reference's broadcasts, OpenMP over traces; 2375-tap CUSP / ZAC by direct convolution and by FFT, the faster one reported; "
+                  f"proxy for the single-threaded Julia reference (not runnable here: no Julia), measured, not extrapolated",
     }
 
 
@@ -401,7 +440,8 @@ def bench_sipm(env, args, n, L):
         # the 12 ragged columns the table keeps (reference :149-156): x, max of the two SG groups, all four fields of the trapezoid groups
         per_group = {"trig": 2, "trig_DC": 2, "trig_trap": 4, "trig_DC_trap": 4}
         elems = sum(int(bufs[1][g]["count"].sum()) * per_group[g] for g in bufs[1])
-        bytes_per_trace = 4 * L + 4 * 20 + 8.0 * elems / n      # measured ragged element count
+        bytes_per_trace = 4 * L + 4 * 20 + 4.0 * elems / n      # measured ragged element count; the kernel stores 4-byte elements
+        # (SURVEY 8(d) C5 prices the reference's Float64 columns, 8 B per element; the slabs this kernel writes hold float32)
         achieved = n * bytes_per_trace / (kms * 1e-3) / 1e9
         wps = n * world * args.steps / elapsed
         res = {
@@ -442,6 +482,15 @@ def run_rank(args):
                 del wf
                 env.torch.cuda.empty_cache()
                 sec.append(bench_sipm(env, args, 625_000, 16384))         # BASELINE config 5's single-GPU shard
+                # parameter sets that do NOT take the kernel above: a trace length that does not fill the tile ->
+                # icpc_kernel (the generic kernel); CUSP and ZAC optimised separately (pars_filter) -> the two-pass instantiation
+                import legenddsp_jl_amd as ldsp
+                us = ldsp.us
+                r_gen, _ = bench_icpc(env, args, 262_144, 8000, "icpc", label="fallback: 262144 x 8000 f32 (the trace does not fill the tile -> generic icpc_kernel)")
+                sec.append(r_gen)
+                r_sep, _ = bench_icpc(env, args, 262_144, 8192, "icpc", pars_filter={"cusp": {"rt": 4.0 * us, "ft": 1.5 * us}, "zac": {"rt": 5.5 * us, "ft": 2.0 * us}},
+                                      label="262144 x 8192 f32, CUSP and ZAC optimised separately (pars_filter): two passes of the closed-form stage in one launch")
+                sec.append(r_sep)
                 res["secondary"] = sec
         if env.rank == 0:
             print(json.dumps(res), flush=True)

@@ -16,7 +16,7 @@ from .routines import (ArrayOfRDWaveforms, Table, dsp_icpc, dsp_sipm, dsp_sipm_c
 from .filters import (SamplingInfo, smplinfo, fltinstance, rdfilt_, flt_output_length, flt_input_length,
                       flt_output_time_axis, InvCRFilter, IntegratorFilter, TrapezoidalChargeFilter, CUSPChargeFilter,
                       ZACChargeFilter, SavitzkyGolayFilter, DerivativeFilter, HaarAveragingFilter, MovingWindowFilter,
-                      MovingWindowMultiFilter, TruncateFilter, shift_waveform, multiply_waveform, reverse_waveform)
+                      MovingWindowMultiFilter, TruncateFilter, TimeAxisFilter, shift_waveform, multiply_waveform, reverse_waveform)
 from .optimization import (dsp_trap_rt_optimization, dsp_trap_ft_optimization, dsp_cusp_rt_optimization, dsp_zac_rt_optimization,
                            dsp_cusp_ft_optimization, dsp_zac_ft_optimization, dsp_sg_optimization, dsp_sg_optimization_compressed, dsp_qc_flt_optimization, dsp_qc_flt_optimization_compressed, dsp_qdrift_flt_optimization, trap_grid_run, fir_grid_run, lower_trap_grid,
                            cuspzac_grid_taps)

@@ -86,6 +86,7 @@ static int ctx_build(ldsp_ctx* c) {
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipEventCreate(&c->evm));
+  HIP_TRY(hipEventCreateWithFlags(&c->evs, hipEventDisableTiming));
   return LDSP_OK;
 }
 
@@ -118,21 +119,31 @@ int ldsp_ctx_destroy(ldsp_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->evm) (void)hipEventDestroy(c->evm);
+  if (c->evs) (void)hipEventDestroy(c->evs);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return LDSP_OK;
 }
 
+// The context's workspaces (filter tables, slabs, the two-kernel scratch) are reused by every launch: work queued on the
+// previous stream may still be reading them when the first launch on the new stream overwrites them.  A change of stream
+// therefore orders the new stream behind everything queued on the old one (event + stream wait, no host synchronisation).
+static int switch_stream(ldsp_ctx* c, hipStream_t next) {
+  if (next == c->stream) return LDSP_OK;
+  HIP_TRY(hipEventRecord(c->evs, c->stream));
+  HIP_TRY(hipStreamWaitEvent(next, c->evs, 0));
+  c->stream = next;
+  return LDSP_OK;
+}
+
 int ldsp_ctx_set_stream(ldsp_ctx* c, void* s) {
   if (!c) return fail(LDSP_ERR_INVALID_ARG, "ctx is NULL");
-  c->stream = reinterpret_cast<hipStream_t>(s);
-  return LDSP_OK;
+  return switch_stream(c, reinterpret_cast<hipStream_t>(s));
 }
 
 int ldsp_ctx_use_own_stream(ldsp_ctx* c) {
   if (!c) return fail(LDSP_ERR_INVALID_ARG, "ctx is NULL");
-  c->stream = c->own_stream;
-  return LDSP_OK;
+  return switch_stream(c, c->own_stream);
 }
 
 int ldsp_ctx_synchronize(ldsp_ctx* c) {

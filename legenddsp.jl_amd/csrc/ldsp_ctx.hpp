@@ -65,6 +65,7 @@ struct ldsp_ctx {
   // timing
   int timing = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;  // evm: boundary between the two dsp_icpc kernels
+  hipEvent_t evs = nullptr;                                 // orders a newly set stream behind the previous one
   int n_launches = 0, n_stages = 1;
   const char* last_kernel = "";   // dominant kernel of the last ldsp_*_run call (static string)
 };

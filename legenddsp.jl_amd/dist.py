@@ -75,8 +75,9 @@ def gather_ragged(values: torch.Tensor, counts: torch.Tensor, n_total: int, dst:
     Three steps: (1) the per-trace counts travel as a one-column table (`gather_table`, fixed size); (2) the root
     scans them: offsets of every trace, and from the shard ranges the element total and start of every peer;
     (3) the payloads, whose sizes differ per peer, travel as point-to-point transfers straight into their place in
-    the result (RCCL: one ncclGroup of send/recv over the direct xGMI links; gloo in the CPU tests).  Peers with no
-    elements send nothing."""
+    the result (RCCL: one ncclGroup of send/recv over the direct xGMI links; gloo in the CPU tests).  A peer with no
+    elements sends nothing and the root posts no receive for it: both sides decide from the same counts (the peer's own sum,
+    the root's scan of the gathered table), so the point-to-point operations always pair up — also when several peers are empty."""
     if values.dim() == 1:
         values = values[:, None]
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
@@ -84,8 +85,15 @@ def gather_ragged(values: torch.Tensor, counts: torch.Tensor, n_total: int, dst:
         off[1:] = torch.cumsum(counts.to(torch.int64), 0)
         return off, values
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if int(values.shape[0]) != int(counts.sum()):
-        raise ValueError("values must hold exactly sum(counts) rows")
+    # Argument check BEFORE any data moves, and agreed on by every rank: a rank that raised on its own would leave the others
+    # blocked in the gather below for ever (and a payload that does not match its counts would desynchronise the transfers).
+    lo_, hi_ = shard_range(n_total, world, rank)
+    ok = torch.tensor([1 if (int(values.shape[0]) == int(counts.sum()) and int(counts.shape[0]) == hi_ - lo_) else 0],
+                      dtype=torch.int32, device=counts.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        raise ValueError("gather_ragged: on some rank `values` does not hold exactly sum(counts) rows, or `counts` is not that "
+                         "rank's shard of n_total traces (checked on every rank: all of them raise)")
     cnt = gather_table(counts.to(torch.int64)[:, None].contiguous(), n_total, dst=dst, group=group)
     if rank != dst:
         if values.shape[0] > 0:

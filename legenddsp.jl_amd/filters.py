@@ -282,6 +282,32 @@ class TruncateFilter(AbstractRadSigFilter):
         return _SimpleInstance(si, _affine(None, si.n, a, b, 1.0, 0.0, None, 0, b - a + 1), n_out=b - a + 1, t_shift=a)
 
 
+class TimeAxisFilter(AbstractRadSigFilter):
+    """`TimeAxisFilter(period, offset = 0)` — reference src/timeaxis.jl:31-60: the sampling step of the time axis becomes `period`,
+    its first point moves by `offset`; the samples are unchanged (`rdfilt!` copies them, :60 — here the output shares the input's
+    storage unless the caller supplies y).  Only range time axes exist in this package (the `ArgumentError` of :57 has no trigger)."""
+
+    def __init__(self, period: float, offset: float = 0.0):
+        self.period, self.offset = float(period), float(offset)
+
+    def fltinstance(self, si: SamplingInfo) -> FilterInstance:
+        flt = self
+
+        class _Inst(FilterInstance):
+            def flt_output_time_axis(self):
+                return self.si.t_first + flt.offset, flt.period
+
+            def rdfilt_(self, y, x):
+                if y.data_ptr() != x.data_ptr():
+                    y.copy_(x)
+                return y
+        return _Inst(si)
+
+    def __call__(self, wvfs: ArrayOfRDWaveforms) -> ArrayOfRDWaveforms:
+        t0, dt = self.fltinstance(smplinfo(wvfs)).flt_output_time_axis()
+        return ArrayOfRDWaveforms(wvfs.signal, t0, dt)
+
+
 def shift_waveform(wvfs: ArrayOfRDWaveforms, c) -> ArrayOfRDWaveforms:
     """`shift_waveform.(wvfs, c)` — c a scalar or one value per trace (src/dsp_icpc.jl:105)."""
     per = c if isinstance(c, torch.Tensor) else None

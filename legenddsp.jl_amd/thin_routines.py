@@ -7,7 +7,7 @@ import torch
 
 from .config import DSPConfig
 from .extractors import IntersectMaximum, extremestats, saturation, signalstats, tailstats
-from .filters import SavitzkyGolayFilter, TrapezoidalChargeFilter, shift_waveform
+from .filters import SavitzkyGolayFilter, TimeAxisFilter, TrapezoidalChargeFilter, shift_waveform
 from .routines import ArrayOfRDWaveforms, Table, get_threshold
 
 _US = 1000.0  # ns per us
@@ -52,7 +52,7 @@ def dsp_pmts(data: Table, config: dict) -> Table:
         raise NotImplementedError("WeightedSavitzkyGolayFilter (reference src/alternative_filters.jl) is out of scope; wsg_weight = 0 "
                                   "selects the plain SavitzkyGolayFilter (src/dsp_pmts.jl:44-45)")
     w0: ArrayOfRDWaveforms = data["waveform"]
-    wvfs = ArrayOfRDWaveforms(w0.signal, w0.t_first, float(cfg["time_axis_step_length"]))   # TimeAxisFilter: offset 0
+    wvfs = TimeAxisFilter(float(cfg["time_axis_step_length"]))(w0)   # src/dsp_pmts.jl:23
     bl = signalstats(wvfs, cfg["baseline_window_start"], cfg["baseline_window_end"])
     wf_blsub = shift_waveform(wvfs, -bl["mean"])
     raw = extremestats(wf_blsub)

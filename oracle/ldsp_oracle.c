@@ -470,11 +470,59 @@ int orc_trap(const real* x, int n, int navg, int ngap, int navg2, real* y) {
   }
   return nout;
 }
+/* ---- FFT form of the long FIR filters (CPU-baseline leg only).  RadiationDetectorDSP's ConvolutionFilter offers direct and FFT
+ * convolution ("upstream uses FFT or direct convolution"); which one dsp_icpc's 2375-tap CUSP / ZAC filters take
+ * upstream is not visible in /root/reference.  orc_set_fir_mode(1) makes orc_fir evaluate filters of more than 64 taps as ONE
+ * zero-padded complex radix-2 FFT of the trace, a product with the taps' transform and an inverse FFT (same valid-mode output
+ * to ~1e-12 relative in double): bench.py times both forms and labels them.  The checker (tests/) uses the direct form. */
+static int g_fir_mode = 0;
+void orc_set_fir_mode(int m) { g_fir_mode = m; }
+static void fft_c2(double* re, double* im, int n, int inverse) {   /* in place, n a power of two */
+  for (int i = 1, j = 0; i < n; ++i) {
+    int bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { double t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+  }
+  for (int len = 2; len <= n; len <<= 1) {
+    const double ang = (inverse ? 2.0 : -2.0) * M_PI / len;
+    const double wr = cos(ang), wi = sin(ang);
+    for (int i = 0; i < n; i += len) {
+      double cr = 1.0, ci = 0.0;
+      for (int k = 0; k < len / 2; ++k) {
+        const int a = i + k, b2 = i + k + len / 2;
+        const double xr = re[b2] * cr - im[b2] * ci, xi = re[b2] * ci + im[b2] * cr;
+        re[b2] = re[a] - xr; im[b2] = im[a] - xi;
+        re[a] += xr; im[a] += xi;
+        const double t = cr * wr - ci * wi; ci = cr * wi + ci * wr; cr = t;
+      }
+    }
+  }
+  if (inverse) { const double s = 1.0 / n; for (int i = 0; i < n; ++i) { re[i] *= s; im[i] *= s; } }
+}
+static int fir_fft(const real* x, int n, const double* h, int m, real* y) {
+  const int nout = n - m + 1;
+  int N = 1;
+  while (N < n + m - 1) N <<= 1;
+  double* buf = (double*)malloc(sizeof(double) * 4 * (size_t)N);
+  if (!buf) return ORC_ERR_ARG;
+  double *xr = buf, *xi = buf + N, *hr = buf + 2 * N, *hi = buf + 3 * N;
+  for (int i = 0; i < N; ++i) { xr[i] = i < n ? (double)x[i] : 0.0; xi[i] = 0.0; hr[i] = i < m ? h[i] : 0.0; hi[i] = 0.0; }
+  fft_c2(xr, xi, N, 0);
+  fft_c2(hr, hi, N, 0);
+  for (int i = 0; i < N; ++i) { const double a = xr[i] * hr[i] - xi[i] * hi[i], b2 = xr[i] * hi[i] + xi[i] * hr[i]; xr[i] = a; xi[i] = b2; }
+  fft_c2(xr, xi, N, 1);
+  for (int k = 0; k < nout; ++k) y[k] = (real)xr[k + m - 1];   /* full convolution index k + m - 1 = valid-mode output k */
+  free(buf);
+  return nout;
+}
+
 /* Valid-mode true convolution y[k] = sum_j h[j] x[k+m-1-j] (ConvolutionFilter) */
 int orc_fir(const real* x, int n, const double* h, int m, real* y) {
   int nout = n - m + 1;
   if (m < 1) return ORC_ERR_ARG;
   if (nout < 1) return ORC_ERR_WINDOW;
+  if (g_fir_mode == 1 && m > 64) return fir_fft(x, n, h, m, y);
   real* hr = (real*)malloc(sizeof(real) * (size_t)m);
   for (int j = 0; j < m; ++j) hr[j] = h[m - 1 - j];
   /* tap-outer / output-inner: each y[k] still accumulates its taps in ascending

@@ -203,6 +203,11 @@ def sg_coeffs(npts, degree, deriv):
 
 # ---- fused routines -----------------------------------------------------------
 
+def set_fir_mode(fft: bool):
+    """CPU-baseline leg only: evaluate the long FIR filters (CUSP / ZAC) by FFT instead of direct convolution (ldsp_oracle.c)."""
+    lib().orc_set_fir_mode(1 if fft else 0)
+
+
 def dsp_icpc(wf, params: _abi.IcpcParams, nthreads=1, strict=True, f32=False):
     """wf: [n][L] float32 -> dict of float64 columns in _abi.ICPC_COLS order.  f32: the Float32-typed restatement (what the
     reference computes for Float32 input), for the per-column float32 envelope of tests/parity.py."""

@@ -45,6 +45,42 @@ def test_icpc_one_million_traces(orc):
     assert bool(((e10410 - cols["e_10410"]).abs() <= 0.02 + 3e-6 * cols["e_10410"].abs()).all())
 
 
+def test_icpc_config4_shard_on_the_root_rank():
+    """BASELINE config 4 (10 M x 8192 over 8 GPUs) as rank 0 holds it: a 1.25 M-trace shard (41 GB), the two output tables the
+    gather pipeline alternates between, and the two [10 M, 48] gathered tables only the root allocates (bench.py, N > 1).
+    One GPU cannot run the other seven shards at once, so the gathers are stood in for by device copies of the shard's
+    table into its row block; what is checked is that the whole allocation fits beside the kernel's own needs and that
+    the shard's rows, processed under that memory load, are the rows of the same traces processed alone (bitwise)."""
+    world, n, L = 8, 1_250_000, 8192
+    if _free_gib() < 64:
+        pytest.skip("needs 64 GiB of free HBM")
+    p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, L, 0.0, 16.0)
+    ncol = len(ldsp._abi.ICPC_COLS)
+    wf = torch.empty((n, L), dtype=torch.float32, device="cuda")
+    ldsp.synth.hpge_batch(n, L, device="cuda", out=wf, first_trace=0)
+    outs = [torch.full((n, ncol), float("nan"), dtype=torch.float32, device="cuda") for _ in range(2)]
+    gathered = [torch.full((n * world, ncol), float("nan"), dtype=torch.float32, device="cuda") for _ in range(2)]
+    ctx = ldsp.Context(0)
+    for k in range(4):                                       # four batches through the double buffers
+        ldsp.icpc_run(wf, p, ctx, out=outs[k % 2])
+        blocks = gathered[k % 2].split(n, dim=0)             # the row blocks the RCCL gather writes (dist.gather_table)
+        blocks[0].copy_(outs[k % 2])
+        blocks[world - 1].copy_(outs[k % 2])
+    torch.cuda.synchronize()
+    assert ctx.last_kernel_name() == "lean3::icpc_lean3_kernel"
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    for g in gathered:
+        assert torch.equal(g[:n].view(torch.int32), outs[0].view(torch.int32))
+        assert torch.equal(g[-n:].view(torch.int32), outs[0].view(torch.int32))
+        assert bool(torch.isnan(g[n:-n]).all())              # nothing written outside the two blocks
+    cols = ldsp.table_columns(outs[0])
+    for c in ("blmean", "e_max", "e_trap", "e_cusp", "e_zac", "t50"):
+        assert bool(torch.isfinite(cols[c]).all()), c
+    for a in (0, 624_640, n - 2048):
+        sub = ldsp.icpc_run(wf[a:a + 2048].contiguous(), p)
+        assert torch.equal(sub.view(torch.int32), outs[0][a:a + 2048].view(torch.int32)), a
+
+
 def test_sipm_625k_traces(orc):
     n, L = 625_000, 16384
     if _free_gib() < 60:

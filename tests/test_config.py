@@ -57,3 +57,29 @@ def test_sipm_lowering():
     assert repr(p.trap) == "Trap(6,3,6)" and (p.trap_mintot, p.trap_maxtot) == (3, 16)
     assert (p.trunc_from, p.trunc_until) == (2938, 3312)
     assert p.pz_c == pytest.approx(16 / 3000)
+
+
+def test_time_axis_filter_reference_cases():
+    """reference test/test_timeaxis.jl:7-55: the step is overwritten, the first point moves by the offset, the samples stay; a batch
+    gives what a single waveform gives, with one shared axis.  (Metadata only: runs without a device.)"""
+    import numpy as np
+    import torch
+    import legenddsp_jl_amd as ldsp
+    rng = np.random.default_rng(7)
+    old_offset, old_step, new_offset, new_step = rng.random(4)
+    wf = ldsp.ArrayOfRDWaveforms(torch.from_numpy(rng.random((1, 100)).astype(np.float32)), float(old_offset), float(old_step))
+    out = ldsp.TimeAxisFilter(float(new_step), float(new_offset))(wf)
+    assert out.t_first == float(old_offset) + float(new_offset) and out.dt == float(new_step)          # :24-25
+    assert torch.equal(out.signal, wf.signal) and out.nsamples == 100
+    to0 = ldsp.TimeAxisFilter(4.0, -wf.t_first)(wf)                                                    # :28-32
+    assert to0.t_first == 0.0 and to0.dt == 4.0
+    wfs = ldsp.ArrayOfRDWaveforms(torch.from_numpy(rng.random((10, 100)).astype(np.float32)), 0.0, 16.0)   # :35-53
+    flt = ldsp.TimeAxisFilter(4.0, 100.0)
+    new = flt(wfs)
+    one = flt(ldsp.ArrayOfRDWaveforms(wfs.signal[:1], 0.0, 16.0))
+    assert len(new) == 10 and (new.t_first, new.dt) == (one.t_first, one.dt) == (100.0, 4.0)
+    assert torch.equal(new.signal[:1], one.signal)
+    fi = ldsp.fltinstance(flt, ldsp.smplinfo(wfs))                                                     # the protocol functions
+    assert ldsp.flt_output_length(fi) == ldsp.flt_input_length(fi) == 100 and ldsp.flt_output_time_axis(fi) == (100.0, 4.0)
+    y = torch.empty_like(wfs.signal)
+    assert torch.equal(ldsp.rdfilt_(y, fi, wfs.signal), wfs.signal)

@@ -162,6 +162,53 @@ def test_gather_ragged_gloo(n):
         assert (out[off[i]:off[i + 1], 0] == i).all()
 
 
+def _ragged_worker4(rank, world, port, n, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = ldist.shard_range(n, world, rank)
+    idx = torch.arange(lo, hi)
+    cnt = torch.where(torch.tensor(rank in (0, 3)), (idx * 3) % 4 + 1, torch.zeros_like(idx))   # ranks 1 and 2: no element at all
+    vals = torch.repeat_interleave(idx, cnt).to(torch.float32)[:, None]
+    if mode == "bad" and rank == 2:
+        vals = torch.zeros((3, 1))          # a payload that does not match its counts, on ONE rank
+    try:
+        res = ldist.gather_ragged(vals, cnt.to(torch.int32), n, dst=0)
+        if rank == 0:
+            q.put(("ok", res[0].numpy(), res[1].numpy()))
+    except ValueError:
+        q.put(("raised", rank, None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["empty_peers", "bad"])
+def test_gather_ragged_world4_empty_peers_and_collective_check(mode):
+    """world 4 (gloo): two of the three peers have no element — the root posts no receive for them and they send nothing; and a
+    payload that does not match its counts on ONE rank makes EVERY rank raise (the check is an all-reduce in front of the
+    transfers: nobody is left waiting in the gather)."""
+    n, world = 22, 4
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker4, args=(r, world, port, n, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(1 if mode == "empty_peers" else world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    if mode == "bad":
+        assert sorted(g[1] for g in got) == [0, 1, 2, 3] and all(g[0] == "raised" for g in got)
+        return
+    _, off, out = got[0]
+    idx = np.arange(n)
+    owner = np.array([next(r for r in range(world) if ldist.shard_range(n, world, r)[0] <= i < ldist.shard_range(n, world, r)[1]) for i in idx])
+    cnt = np.where(np.isin(owner, (0, 3)), (idx * 3) % 4 + 1, 0)
+    assert np.array_equal(np.diff(off), cnt)
+    np.testing.assert_array_equal(out[:, 0], np.repeat(idx, cnt).astype(np.float32))
+
+
 def test_gather_ragged_single_process():
     cnt = torch.tensor([2, 0, 3], dtype=torch.int32)
     vals = torch.arange(5, dtype=torch.float32)

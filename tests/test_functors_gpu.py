@@ -305,6 +305,19 @@ def test_extractors_match_oracle(orc, batch):
     np.testing.assert_allclose(host(t50), host(fused["t50"]), atol=5e-4)
     qd = ldsp.get_qdrift(pzd, fused["t0"], (2500.0, 5000.0))
     np.testing.assert_allclose(host(qd), host(fused["qdrift"]), rtol=2e-4, atol=40)
+    # get_intracePileUp (src/dsp_routines.jl:72-82) on the Savitzky-Golay derivative, as dsp_icpc.jl:181,189 calls it: the
+    # statement-by-statement spelling through the functor entry points gives the fused table's columns
+    cfg = ldsp.reference_test_icpc_config()
+    sg = ldsp.SavitzkyGolayFilter(ldsp.get_fltpars({}, "sg", cfg), cfg.sg_flt_degree, 1)(pzd)
+    pu = ldsp.get_intracePileUp(sg, float(cfg.inTraceCut_std_threshold), (cfg.bl_window.left, cfg.bl_window.right),
+                                mintot=p.intrace_mintot * DT)
+    n_f, x_f = host(fused["inTrace_n"]), host(fused["inTrace_intersect"])
+    n_u, x_u = host(pu["n"]), host(pu["intersect"])
+    same = n_u == n_f
+    assert same.mean() >= 0.97, (n_u[~same], n_f[~same])          # a count may differ where a run barely holds (float32 sigma)
+    both = same & np.isfinite(x_f)
+    np.testing.assert_allclose(x_u[both], x_f[both], atol=0.6)
+    assert np.array_equal(np.isnan(x_u[same]), np.isnan(x_f[same]))
 
 
 def test_intersect_maximum_returns_every_crossing_beyond_the_slab(orc):

@@ -101,3 +101,32 @@ def test_sg_coefficients_equal_scipy(orc):
     from scipy.signal import savgol_coeffs
     for n, d, der in ((5, 2, 1), (7, 3, 1), (13, 3, 1), (7, 2, 0), (9, 4, 2), (3, 2, 1)):
         np.testing.assert_allclose(orc.sg_coeffs(n, d, der), savgol_coeffs(n, d, deriv=der, use="conv"), atol=1e-13)
+
+
+def test_fft_form_of_the_fir_filters_equals_the_direct_form(orc):
+    # The CPU baseline is timed in both forms (bench.py `cpu_baseline.forms`): the direct valid-mode convolution the
+    # parity tests use, and the overlap-free FFT form a tuned CPU library would take for the 2375-tap CUSP/ZAC filters.
+    # They are the same linear map: outputs agree to the rounding of a length-16384 double transform.
+    rng = np.random.default_rng(11)
+    x = 1000.0 + 50.0 * rng.standard_normal(8192) + np.where(np.arange(8192) > 3000, 9000.0, 0.0)
+    h = orc.cusp_coeffs(ldsp._abi.CuspZac(312.5, 156, 2375, 1e10, 2375.0))
+    try:
+        orc.set_fir_mode(False)
+        direct = orc.fir(x, h)
+        orc.set_fir_mode(True)
+        viafft = orc.fir(x, h)
+    finally:
+        orc.set_fir_mode(False)
+    assert direct.shape == viafft.shape == (8192 - len(h) + 1,)
+    assert np.abs(direct - viafft).max() <= 1e-9 * np.abs(direct).max()
+    # and through the whole chain: same table
+    p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, 8192, 0.0, 16.0)
+    wf = ldsp.synth.hpge_batch(8, 8192, seed=3).numpy()
+    try:
+        a = orc.dsp_icpc(wf, p)
+        orc.set_fir_mode(True)
+        b = orc.dsp_icpc(wf, p)
+    finally:
+        orc.set_fir_mode(False)
+    for k in a:
+        np.testing.assert_allclose(b[k], a[k], rtol=1e-9, atol=1e-9, equal_nan=True, err_msg=k)

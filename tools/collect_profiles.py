@@ -13,6 +13,20 @@ with open(os.path.join(dst, f"{tag}_bench.json"), "w") as f:
     f.write(line + "\n")
 bench = json.loads(line)
 shutil.copy(os.path.join(src, "stats", "p_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+# the same run's kernel trace without each kernel's FIRST launch (cold instruction cache / clocks): what the bench's timed steps see
+kt = os.path.join(src, "stats", "p_kernel_trace.csv")
+if os.path.exists(kt):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt)):
+        if r["Kernel_Name"].startswith("void ldsp::"):
+            per[r["Kernel_Name"].replace("void ", "").split("(")[0]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    with open(os.path.join(dst, f"{tag}_bench_kernel_stats_warm.csv"), "w") as g:
+        g.write("kernel,launches,first_launch_ns,warm_launches,warm_avg_ns,warm_min_ns,warm_max_ns\n")
+        for k, v in sorted(per.items()):
+            v.sort()
+            d = [x[1] for x in v]
+            w = d[1:] if len(d) > 1 else d
+            g.write(f'"{k}",{len(d)},{d[0]},{len(w)},{sum(w) / len(w):.0f},{min(w)},{max(w)}\n')
 for t in ("gpu_time_grid", "gpu_time_compressed", "gpu_time_multi_intersect"):
     ks = os.path.join(src, f"stats_{t}", "p_kernel_stats.csv")
     if os.path.exists(ks):
@@ -22,10 +36,15 @@ for t in ("gpu_time_grid", "gpu_time_compressed", "gpu_time_multi_intersect"):
         with open(lg) as f, open(os.path.join(dst, f"{tag}_{t[9:]}_timing.txt"), "w") as g:
             g.write("".join(l for l in f if "amdgpu.ids" not in l and not l.startswith("[rocprofv3]") and "rocprofiler" not in l))
 # workloads of the bench command: kernel-name fragment -> (n_traces, L)
-shapes = {"icpc": (bench["config"]["traces_per_gpu"], bench["config"]["samples"])}
+# (the headline kernel is the shared-geometry instantiation <.., false>; the secondary dsp_icpc lines run the two-pass instantiation
+# <.., true> and the generic icpc_kernel)
+shapes = {"icpc_lean3_kernel": (bench["config"]["traces_per_gpu"], bench["config"]["samples"])}
 for sec in bench.get("secondary", []):
-    key = "pz_trap" if "pole-zero" in sec["metric"] else "k_sipm"
-    shapes[key] = (sec["config"]["traces_per_gpu"], sec["config"]["samples"])
+    shp = (sec["config"]["traces_per_gpu"], sec["config"]["samples"])
+    if "pole-zero" in sec["metric"]: shapes["pz_trap"] = shp
+    elif "dsp_sipm" in sec["metric"]: shapes["k_sipm"] = shp
+    elif "separately" in sec["config"]["workload"]: shapes["true>"] = shp
+    elif "fallback" in sec["config"]["workload"]: shapes["icpc_kernel<"] = shp
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for ctr, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     per_dispatch = collections.defaultdict(float)
@@ -37,7 +56,7 @@ for ctr, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         acc[names[k].replace("void ", "").split("(")[0]][ctr].append(v)
 recs = []
 for k, v in acc.items():
-    shape = next((s for frag, s in shapes.items() if frag in k), None)
+    shape = shapes.get("true>") if ("icpc_lean3_kernel" in k and k.rstrip().endswith("true>")) else next((s for frag, s in shapes.items() if frag in k and frag != "true>"), None)
     if shape is None or not v["FETCH_SIZE"] or not v["WRITE_SIZE"]:
         continue
     fa, wa = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])

@@ -4,14 +4,14 @@
 # same bench command, then kernel statistics of the "next" rows (grid scans, qc features, compressed routines, MultiIntersect)
 # -> gpurun_out/<tag>/ ; tools/collect_profiles.py <tag> copies the judged summaries into profiles/.
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | cut -c1-300
-rocprofv3 --kernel-trace --stats -d $O/stats -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -o p --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --cpu-sample 0 > $O/stats.log 2>&1
 echo "stats done"
 # HBM traffic: one pass per counter (MI355X_MICROARCH.md, HBM / rocprofv3 section), nothing else traced
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/pmc_fetch.log 2>&1
