@@ -164,10 +164,12 @@ def timed(env, args, step, finish=lambda: None):
 
 
 # Compute-issue ceilings of the full dsp_icpc chain at L = 8192 (waveforms/s per GPU):
-#   "algorithmic": ~130 flop per sample at 0.5 plain VALU instructions per SIMD cycle, perfectly packed (round 2's estimate);
-#   "instruction_stream": the VALU instructions icpc_lean3_kernel actually issues (3 430 per wave of 16 samples per lane,
-#   profiles/r03_phase_counters.txt) at the measured mix of 2- and 4-cycle instructions (~2.5 cycles each) on 1 024 SIMDs at 2.4 GHz.
-ISSUE_CEILING_ICPC = {"algorithmic": 65.0e6, "instruction_stream": 35.8e6}
+#   "algorithmic": the minimum arithmetic of the restructured chain (~85 VALU operations per sample) at the measured issue costs
+#   (profiles/r03_micro_issue_costs.txt), perfectly packed, no LDS or barrier time;
+#   "instruction_stream": the instructions icpc_lean3_kernel actually issues — 3 690 VALU per wave of 16 samples per lane
+#   (profiles/r03_lean3_phase_insts.txt), of which 46 % are moves / selects / compares / DPP (profiles/r03_lean3_valu_mix.txt) —
+#   priced per class at those costs: ~12 k VALU-pipe cycles per wave, 8 waves per trace, 1 024 SIMDs at 2.4 GHz.
+ISSUE_CEILING_ICPC = {"algorithmic": 65.0e6, "instruction_stream": 25.6e6}
 
 
 def roofline(achieved_gbs, kernel, kernel_ms, bytes_per_trace, traffic, issue_of=None):

@@ -1,4 +1,4 @@
-# LegendDSPHIP.jl — Julia host side of libldsp_hip.so (include/ldsp.h, ABI version 2): what a LegendDSP.jl maintainer
+# LegendDSPHIP.jl — Julia host side of libldsp_hip.so (include/ldsp.h, ABI version 3): what a LegendDSP.jl maintainer
 # adds as a package extension so that `dsp_icpc` / `dsp_sipm` and the filter functors / extractors they are built from run
 # on an MI355X for batches that live in AMDGPU.ROCArray memory.
 #

@@ -41,7 +41,7 @@ lean3 = {0: "start", 1: "load, raw extremes, baseline sums, prefix scans of x'",
          8: "barrier", 9: "y -> X, SG masks from registers", 10: "barrier", 11: "run scans on the masks, threshold confirmation", 12: "barrier",
          13: "t50_current / pile-up position, finishing lanes, crossings", 14: "estimators, parabolas (waves 0-3)", 15: "yprev, p0, barrier",
          16: "CZ: Dp -> X + barrier",
-         17: "CZ: u (ZAC taps) -> X + 2 barriers", 18: "CZ: double cumsum -> X, readback, Dp -> X + 4 barriers", 19: "CZ: flat top, d",
+         17: "CZ: u (ZAC tap chain), flat top, u -> X + 2 barriers", 18: "CZ: double cumsum -> X + 2 barriers, readback", 19: "CZ: d",
          20: "CZ: causal scan + readback", 21: "CZ: anti-causal scan + readback", 22: "CZ: maxima, estimator points", 23: "CZ: collect"}
 kn = ctx.last_kernel_name()
 names = lean3 if "lean3" in kn else lean if "lean" in kn else generic
