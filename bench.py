@@ -439,18 +439,20 @@ def bench_sipm(env, args, n, L):
     res = None
     if rank == 0:
         kms = sum(kms) / len(kms)
-        # the 12 ragged columns the table keeps (reference :149-156): x, max of the two SG groups, all four fields of the trapezoid groups
+        # the 12 ragged columns the table keeps (reference :149-156): x, max of the two SG groups, all four fields of the trapezoid
+        # groups; positions (x, x_high, x_tot) are stored as Float64 (8 B), maxima as float32 (4 B): what the kernel writes
+        bytes_per_trig = {"trig": 8 + 4, "trig_DC": 8 + 4, "trig_trap": 3 * 8 + 4, "trig_DC_trap": 3 * 8 + 4}
         per_group = {"trig": 2, "trig_DC": 2, "trig_trap": 4, "trig_DC_trap": 4}
-        elems = sum(int(bufs[1][g]["count"].sum()) * per_group[g] for g in bufs[1])
-        bytes_per_trace = 4 * L + 4 * 20 + 4.0 * elems / n      # measured ragged element count; the kernel stores 4-byte elements
-        # (SURVEY 8(d) C5 prices the reference's Float64 columns, 8 B per element; the slabs this kernel writes hold float32)
+        counts = {g: int(bufs[1][g]["count"].sum()) for g in bufs[1]}
+        elems = sum(counts[g] * per_group[g] for g in counts)
+        bytes_per_trace = 4 * L + 4 * 20 + sum(counts[g] * bytes_per_trig[g] for g in counts) / n
         achieved = n * bytes_per_trace / (kms * 1e-3) / 1e9
         wps = n * world * args.steps / elapsed
         res = {
             "metric": "waveforms/s, fused dsp_sipm, 16384-sample f32", "value": wps, "unit": "waveforms/s",
             "msamples_per_s": wps * L / 1e6, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (the reference forces Float64, src/dsp_sipm.jl:87-88)", "data": "synthetic",
+            "dtype": "f32 signal arithmetic, Float64 time axis and trigger positions (the reference forces Float64 throughout, src/dsp_sipm.jl:87-88)", "data": "synthetic",
             "config": {"workload": f"BASELINE config 5 shape: dsp_sipm, {n}{' per GPU' if world > 1 else ''} x {L} f32 traces", "traces_per_gpu": n, "samples": L,
                        "dt_ns": 16.0, "dsp_config": "reference test/test_dsp_sipm.jl:38-68 + sg.wl = 200 ns",
                        "ragged_elements_per_trace": elems / n,

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LDSP_ABI_VERSION 3
+#define LDSP_ABI_VERSION 4
 
 typedef enum {
   LDSP_OK = 0,
@@ -222,7 +222,11 @@ typedef struct {
  * `extractors.resolve_overflow`) — nothing is dropped silently.  cap = 0 means LDSP_MAX_TRIG. */
 typedef struct {
   int32_t* count; /* [n]                    */
-  float *x, *x_high, *x_tot, *max; /* each [n][cap], may be NULL */
+  /* Positions are Float64 like the reference's (src/dsp_sipm.jl:87-88 converts the time axis to Float64; the ragged columns
+   * :149-156 are Vector{Float64}): t_first + dt * (index + fraction) composed in double — a float32 time at 2.6e5 ns has an
+   * ulp of 0.03 ns.  `max` is a sample value / parabola maximum of the float32 signal. */
+  double *x, *x_high, *x_tot;      /* each [n][cap], may be NULL */
+  float* max;                      /* [n][cap], may be NULL */
   int32_t cap;    /* slab capacity per trace (row stride); 0 = LDSP_MAX_TRIG */
   int32_t _pad;
 } ldsp_trig_out;

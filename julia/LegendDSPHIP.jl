@@ -1,4 +1,4 @@
-# LegendDSPHIP.jl — Julia host side of libldsp_hip.so (include/ldsp.h, ABI version 3): what a LegendDSP.jl maintainer
+# LegendDSPHIP.jl — Julia host side of libldsp_hip.so (include/ldsp.h, ABI version 4): what a LegendDSP.jl maintainer
 # adds as a package extension so that `dsp_icpc` / `dsp_sipm` and the filter functors / extractors they are built from run
 # on an MI355X for batches that live in AMDGPU.ROCArray memory.
 #
@@ -21,7 +21,7 @@ import RadiationDetectorDSP: fltinstance, rdfilt!, flt_output_length, flt_input_
     flt_output_time_axis, smplinfo, SamplingInfo, AbstractRadSigFilterInstance, LinearFiltering, NonlinearFiltering
 
 const libldsp = get(ENV, "LDSP_HIP_LIB", joinpath(@__DIR__, "..", "legenddsp.jl_amd", "csrc", "libldsp_hip.so"))
-const LDSP_ABI_VERSION = 3
+const LDSP_ABI_VERSION = 4
 const LDSP_MAX_TRIG = 64
 const LDSP_ICPC_NCOLS = 48
 
@@ -134,9 +134,9 @@ end
 
 struct LdspTrigOut
     count::Ptr{Int32}
-    x::Ptr{Float32}
-    x_high::Ptr{Float32}
-    x_tot::Ptr{Float32}
+    x::Ptr{Float64}        # positions: Float64 like the reference's time axis (src/dsp_sipm.jl:87-88)
+    x_high::Ptr{Float64}
+    x_tot::Ptr{Float64}
     max::Ptr{Float32}
     cap::Int32
     _pad::Int32
@@ -372,12 +372,13 @@ end
 # one trigger group of dsp_sipm: count + four slabs of `cap` entries per trace
 struct TrigBuffers
     count::ROCVector{Int32}
-    x::ROCArray{Float32,2}
-    x_high::ROCArray{Float32,2}
-    x_tot::ROCArray{Float32,2}
+    x::ROCArray{Float64,2}
+    x_high::ROCArray{Float64,2}
+    x_tot::ROCArray{Float64,2}
     max::ROCArray{Float32,2}
 end
-TrigBuffers(n::Integer, cap::Integer) = TrigBuffers(ROCVector{Int32}(undef, n), (ROCArray{Float32}(undef, cap, n) for _ in 1:4)...)
+TrigBuffers(n::Integer, cap::Integer) = TrigBuffers(ROCVector{Int32}(undef, n), (ROCArray{Float64}(undef, cap, n) for _ in 1:3)...,
+                                                    ROCArray{Float32}(undef, cap, n))
 _trig_out(t::TrigBuffers) = LdspTrigOut(devptr(t.count), devptr(t.x), devptr(t.x_high), devptr(t.x_tot), devptr(t.max), Int32(size(t.x, 1)), Int32(0))
 
 # UInt16 ADC counts go through ldsp_sipm_run_u16 (converted by the kernel as it loads them)
@@ -406,7 +407,7 @@ function _sipm_run(x::ROCArray{Float32,2}, p::LdspSipmParams, ctx::LdspCtx, cap:
 end
 
 # VectorOfVectors of one field: every trigger of every trace (the reference pushes every crossing, src/intersect_maximum.jl:49-56)
-function _ragged(field::Matrix{Float32}, count::Vector{Int32}, unit)
+function _ragged(field::Matrix{<:AbstractFloat}, count::Vector{Int32}, unit)
     cap = size(field, 1)
     VectorOfVectors([field[1:min(Int(c), cap), i] .* unit for (i, c) in enumerate(count)])
 end
@@ -430,7 +431,7 @@ function LegendDSP.dsp_sipm(data::Table, config::PropDict, pars_optimization::Pr
         _, g2 = _sipm_run(x[:, rows], p, ctx, nextpow(2, Int(mx)))
         for (k, g) in enumerate(g2)
             f2 = (Array(g.x), Array(g.x_high), Array(g.x_tot), Array(g.max))
-            grown = ntuple(j -> vcat(fields[k][j], fill(NaN32, size(f2[j], 1) - size(fields[k][j], 1), n)), 4)
+            grown = ntuple(j -> vcat(fields[k][j], fill(eltype(f2[j])(NaN), size(f2[j], 1) - size(fields[k][j], 1), n)), 4)
             for (jj, i) in enumerate(rows), j in 1:4
                 grown[j][:, i] .= f2[j][:, jj]
             end

@@ -4,7 +4,7 @@ Pure declarations: importing this module loads no native code.
 """
 import ctypes as C
 
-LDSP_ABI_VERSION = 3
+LDSP_ABI_VERSION = 4
 LDSP_OK = 0
 LDSP_ERR_INVALID_ARG = -1
 LDSP_ERR_WINDOW = -2
@@ -111,6 +111,12 @@ class SipmParams(C.Structure):
 class IcpcOpts(C.Structure):
     """ldsp_icpc_opts: per-call variations of ldsp_icpc_run_opts (explicit arguments, no context state)."""
     _fields_ = [("ext_baseline", C.c_void_p), ("ext_baseline_scale", C.c_double), ("main_only", C.c_int32), ("in_u16", C.c_int32)]
+
+
+# dtype of the slabs of one trigger group (ldsp_trig_out): positions are Float64 like the reference's time axis
+# (src/dsp_sipm.jl:87-88, ragged columns :149-156), `max` is a value of the float32 signal
+TRIG_FIELDS = ("x", "x_high", "x_tot", "max")
+TRIG_DTYPES = {"x": "float64", "x_high": "float64", "x_tot": "float64", "max": "float32"}
 
 
 class TrigOut(C.Structure):

@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) k_intersect(const float* __restrict__ x, 
 
 #include "intersect_maximum_block.inc"
 
-__global__ void __launch_bounds__(256) k_intersect_maximum(const float* __restrict__ x, int L, float t_first, float dt,
+__global__ void __launch_bounds__(256) k_intersect_maximum(const float* __restrict__ x, int L, double t_first, double dt,
                                                            const float* __restrict__ thr, int min_n, int max_n,
                                                            ldsp_trig_out o) {
   extern __shared__ __align__(16) unsigned char raw[];
@@ -725,7 +725,7 @@ int ldsp_intersect_maximum(ldsp_ctx* c, const float* x, int64_t n, int32_t L, do
   if ((rc = set_lds(k_intersect_maximum, b))) return rc;
   ldsp_trig_out o = *out;
   if (o.cap == 0) o.cap = LDSP_MAX_TRIG;
-  hipLaunchKernelGGL(k_intersect_maximum, dim3((unsigned)n), dim3(256), b, c->stream, x, L, (float)t_first, (float)dt, thr, min_n, max_n, o);
+  hipLaunchKernelGGL(k_intersect_maximum, dim3((unsigned)n), dim3(256), b, c->stream, x, L, t_first, dt, thr, min_n, max_n, o);
   LAUNCH_CHECK();
   return LDSP_OK;
 }

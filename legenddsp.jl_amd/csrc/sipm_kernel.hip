@@ -23,6 +23,7 @@ using tb::Scratch;
 struct SipmDev {
   int32_t L, np;
   float t_first, dt, inv_upus;
+  double t_first64, dt64;   // the time axis as given (trigger positions are composed in double)
   int32_t trunc_from, trunc_until;
   float sg_c[LDSP_MAX_SG_PTS];  // correlation taps
   int32_t sg_mintot, sg_maxtot;
@@ -99,6 +100,7 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
   // SavitzkyGolayFilter(wl, degree, 1): g -> B   :99-100   (valid mode, trailing time axis, A1)
   const int np = P.np, ng = L - np + 1;
   const float tg = P.t_first + P.dt * (float)(np - 1);
+  const double tg64 = fma(P.dt64, (double)(np - 1), P.t_first64);   // (trigger positions: double time axis)
   for (int k = tid; k < pad4(L); k += NT) {
     float g = 0.f;
     if (k < ng) for (int i = 0; i < np; ++i) g = fmaf(P.sg_c[i], A[k + i], g);
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
     __syncthreads();
     const ldsp_trig_out& o = out.trig[0];
     const size_t off = b * (size_t)o.cap;
-    const int tot = intersect_maximum_block(B, ng, 1.f, th, P.sg_mintot, P.sg_maxtot, tg, P.dt, bm, sc, o.cap,
+    const int tot = intersect_maximum_block(B, ng, 1.f, th, P.sg_mintot, P.sg_maxtot, tg64, P.dt64, bm, sc, o.cap,
                                             o.x ? o.x + off : nullptr, o.x_high ? o.x_high + off : nullptr,
                                             o.x_tot ? o.x_tot + off : nullptr, o.max ? o.max + off : nullptr, &sc.f[1]);
     if (tid == 0 && o.count) o.count[b] = tot;
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
     __syncthreads();
     const ldsp_trig_out& o = out.trig[v ? 3 : 1];
     const size_t off = b * (size_t)o.cap;
-    const int tot = intersect_maximum_block(B, ng, -1.f, th, P.sg_mintot, P.sg_maxtot, tg, P.dt, bm, sc, o.cap,
+    const int tot = intersect_maximum_block(B, ng, -1.f, th, P.sg_mintot, P.sg_maxtot, tg64, P.dt64, bm, sc, o.cap,
                                             o.x ? o.x + off : nullptr, o.x_high ? o.x_high + off : nullptr,
                                             o.x_tot ? o.x_tot + off : nullptr, o.max ? o.max + off : nullptr, nullptr);
     if (tid == 0 && o.count) o.count[b] = tot;
@@ -170,6 +172,7 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
   __syncthreads();
   const int flen = P.trap.navg + P.trap.ngap + P.trap.navg2, nt = ng - flen + 1;
   const float tt = tg + P.dt * (float)(flen - 1);
+  const double tt64 = fma(P.dt64, (double)(flen - 1), tg64);
   {
     const float i1 = 1.f / (float)P.trap.navg, i2 = 1.f / (float)P.trap.navg2;
     // SiPM shaping times are a few samples: sum the windows directly (a difference of float
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
     __syncthreads();
     const ldsp_trig_out& o = out.trig[2];
     const size_t off = b * (size_t)o.cap;
-    const int tot = intersect_maximum_block(B, nt, 1.f, th, P.trap_mintot, P.trap_maxtot, tt, P.dt, bm, sc, o.cap,
+    const int tot = intersect_maximum_block(B, nt, 1.f, th, P.trap_mintot, P.trap_maxtot, tt64, P.dt64, bm, sc, o.cap,
                                             o.x ? o.x + off : nullptr, o.x_high ? o.x_high + off : nullptr,
                                             o.x_tot ? o.x_tot + off : nullptr, o.max ? o.max + off : nullptr, nullptr);
     if (tid == 0 && o.count) o.count[b] = tot;
@@ -253,6 +256,7 @@ static int sipm_run_impl(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_sip
   memset(&d, 0, sizeof d);
   d.L = L; d.np = p->sg_npts;
   d.t_first = (float)p->t_first; d.dt = (float)p->dt; d.inv_upus = (float)(1.0 / p->unit_per_us);
+  d.t_first64 = p->t_first; d.dt64 = p->dt;
   d.trunc_from = p->trunc_from; d.trunc_until = p->trunc_until;
   std::vector<double> cc;
   if (!hm::sg_corr_coeffs(p->sg_npts, p->sg_degree, 1, cc)) return ldsp_fail(LDSP_ERR_INVALID_ARG, "Savitzky-Golay coefficients");

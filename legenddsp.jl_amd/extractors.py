@@ -80,7 +80,8 @@ class TriggerOverflow(_lib.LdspError):
 def compact_fields(t: dict, fields=("x", "x_high", "x_tot", "max")):
     """Compact the slabs of one trigger group (`count` [n], one [n, cap] slab per field, optionally an `overflow`
     record = the same for the traces whose count exceeded cap, re-run with larger slabs by `resolve_overflow`) into
-    `(values [sum(count), len(fields)], count [n] int64)`: EVERY trigger of every trace, in trace order — what the
+    `(values [sum(count), len(fields)] float64, count [n] int64)` (positions are Float64 slabs, `max` float32 ones: one
+    float64 block holds both exactly): EVERY trigger of every trace, in trace order — what the
     reference's `VectorOfVectors` columns hold (src/intersect_maximum.jl:49-56 pushes every crossing).  Work is
     proportional to the number of triggers, not to n x cap.  Raises TriggerOverflow if a count exceeds its slab and no
     overflow record covers it."""
@@ -97,7 +98,7 @@ def compact_fields(t: dict, fields=("x", "x_high", "x_tot", "max")):
     if ovf is None:
         if total and bool(over.any()):
             raise TriggerOverflow(-104, f"a trace has more than {cap} triggers: call resolve_overflow() first")
-        vals = torch.stack([t[f][row, pos] for f in fields], dim=1) if total else torch.empty((0, len(fields)), dtype=torch.float32, device=dev)
+        vals = torch.stack([t[f][row, pos].to(torch.float64) for f in fields], dim=1) if total else torch.empty((0, len(fields)), dtype=torch.float64, device=dev)
         return vals, count
     slot = torch.full((n,), -1, dtype=torch.int64, device=dev)
     slot[ovf["rows"]] = torch.arange(len(ovf["rows"]), device=dev)
@@ -108,7 +109,7 @@ def compact_fields(t: dict, fields=("x", "x_high", "x_tot", "max")):
     for f in fields:
         a = t[f][row, pos.clamp(max=cap - 1)]
         b = ovf[f][slot[row].clamp(min=0), pos.clamp(max=ovf[f].shape[1] - 1)]
-        cols.append(torch.where(use2, b, a))
+        cols.append(torch.where(use2, b, a).to(torch.float64))
     return torch.stack(cols, dim=1), count
 
 
@@ -117,7 +118,8 @@ def _compact_group(t: dict, fields):
     vals, count = compact_fields(t, fields)
     offsets = torch.zeros(len(count) + 1, dtype=torch.int64, device=count.device)
     offsets[1:] = torch.cumsum(count, 0)
-    return {f: VectorOfVectors(offsets, vals[:, i].contiguous()) for i, f in enumerate(fields)}, count
+    return {f: VectorOfVectors(offsets, vals[:, i].contiguous().to(getattr(torch, _abi.TRIG_DTYPES.get(f, "float64"))))
+            for i, f in enumerate(fields)}, count
 
 
 def resolve_overflow(groups: dict, rerun):
@@ -235,8 +237,10 @@ class IntersectMaximum:
         ctx, x = _prep(w)
         n, dev = x.shape[0], x.device
         if x.shape[1] == 0:   # empty waveforms: empty vectors, multiplicity 0 (reference test/test_intersect_maximum.jl:81-90)
-            empty = lambda: VectorOfVectors(torch.zeros(n + 1, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.float32, device=dev))
-            return dict(x=empty(), x_high=empty(), x_tot=empty(), max=empty(), multiplicity=torch.zeros(n, dtype=torch.int32, device=dev))
+            empty = lambda f: VectorOfVectors(torch.zeros(n + 1, dtype=torch.int64, device=dev),
+                                              torch.empty(0, dtype=getattr(torch, _abi.TRIG_DTYPES[f]), device=dev))
+            return dict(x=empty("x"), x_high=empty("x_high"), x_tot=empty("x_tot"), max=empty("max"),
+                        multiplicity=torch.zeros(n, dtype=torch.int32, device=dev))
         thr = _per_trace(threshold, n, dev)
         min_n, max_n = max(1, nsamples(self.mintot, w.dt)), max(1, nsamples(self.maxtot, w.dt))
         fields = ("x", "x_high", "x_tot", "max")
@@ -244,7 +248,7 @@ class IntersectMaximum:
         def run(xs, ths, cap):
             m = xs.shape[0]
             count = _i(m, dev)
-            slabs = {k: torch.full((m, cap), float("nan"), dtype=torch.float32, device=dev) for k in fields}
+            slabs = {k: torch.full((m, cap), float("nan"), dtype=getattr(torch, _abi.TRIG_DTYPES[k]), device=dev) for k in fields}
             o = _abi.TrigOut(count.data_ptr(), *[slabs[k].data_ptr() for k in fields], cap, 0)
             _lib.check(_lib.lib().ldsp_intersect_maximum(ctx.handle, _vp(xs), m, xs.shape[1], w.t_first, w.dt, _vp(ths), min_n, max_n, C.byref(o)))
             return dict(count=count, **slabs)

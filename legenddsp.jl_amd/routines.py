@@ -168,7 +168,7 @@ def dsp_icpc(data: Table, config: DSPConfig, tau: float, pars_filter: dict, f_ev
 
 def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None, out=None, cap: int = None):
     """Run the fused dsp_sipm kernel (`ldsp_sipm_run`).  Returns (scalars [20, n] float32,
-    {group: {count [n] int32, x/x_high/x_tot/max [n, cap] float32}}), cap = LDSP_MAX_TRIG by default.
+    {group: {count [n] int32, x/x_high/x_tot [n, cap] float64, max [n, cap] float32}}), cap = LDSP_MAX_TRIG by default.
     `count` is the TRUE multiplicity: where it exceeds cap the slab holds the first cap triggers only and
     `sipm_resolve_overflow` (called by `dsp_sipm`) runs those traces again with larger slabs.
     `out`: the pair returned by an earlier call on a batch of the same size — its buffers are reused
@@ -193,14 +193,14 @@ def sipm_run(wf: torch.Tensor, params: _abi.SipmParams, ctx: _lib.Context = None
             if t["count"].shape != (n,) or t["count"].dtype != torch.int32 or t["count"].device != dev:
                 raise ValueError(f"out=: count buffer of group {g} does not match this batch")
             for k in ("x", "x_high", "x_tot", "max"):
-                if t[k].shape != (n, t["x"].shape[1]) or t[k].dtype != torch.float32 or t[k].device != dev or not t[k].is_contiguous():
+                if t[k].shape != (n, t["x"].shape[1]) or t[k].dtype != getattr(torch, _abi.TRIG_DTYPES[k]) or t[k].device != dev or not t[k].is_contiguous():
                     raise ValueError(f"out=: slab {g}.{k} does not match this batch")
     else:
         sc = torch.full((len(_abi.SIPM_SCALAR_COLS), n), float("nan"), dtype=torch.float32, device=dev)
         trig = {}
         for g in _abi.SIPM_TRIG_GROUPS:
             cnt = torch.zeros(n, dtype=torch.int32, device=dev)
-            slabs = {k: torch.full((n, cap), float("nan"), dtype=torch.float32, device=dev) for k in ("x", "x_high", "x_tot", "max")}
+            slabs = {k: torch.full((n, cap), float("nan"), dtype=getattr(torch, _abi.TRIG_DTYPES[k]), device=dev) for k in _abi.TRIG_FIELDS}
             trig[g] = dict(count=cnt, **slabs)
     o = _abi.SipmOut()
     for i, c in enumerate(_abi.SIPM_SCALAR_COLS):

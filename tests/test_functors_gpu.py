@@ -110,6 +110,24 @@ def test_intersect_maximum_reference_values():    # test/test_intersect_maximum.
     assert int(r["multiplicity"][0]) == 0 and len(r["x"][0]) == 0
 
 
+def test_intersect_maximum_positions_are_float64():
+    """The reference's trigger positions are Float64 (src/dsp_sipm.jl:87-88 converts the time axis; the ragged columns of
+    :149-156 are Vector{Float64}).  On a time axis that starts at 1e9 ns a float32 position has an ulp of 64 ns; the slabs
+    are double and composed in double, so the crossing comes out to the rounding of the float32 interpolation fraction."""
+    n, t0 = 4096, 1.0e9
+    f = ldsp.IntersectMaximum(mintot=2 * DT, maxtot=100 * DT)
+    s = np.zeros(n); s[1000:1003] = [0.5, 0.6, 0.2]; s[3000:3006] = [0.25, 0.5, 0.75, 1.0, 0.5, 0.1]
+    r = f(wv(s, t0, DT), 0.4)
+    assert r["x"].values.dtype == r["x_high"].values.dtype == r["x_tot"].values.dtype == torch.float64
+    assert r["max"].values.dtype == torch.float32
+    x, xh, xt = (host(r[k][0]) for k in ("x", "x_high", "x_tot"))
+    exp_x = np.array([t0 + DT * (999 + 0.4 / 0.5), t0 + DT * (3000 + (0.4 - 0.25) / 0.25)])
+    exp_h = np.array([t0 + DT * (1001 + (0.4 - 0.6) / (0.2 - 0.6)), t0 + DT * (3004 + (0.4 - 0.5) / (0.1 - 0.5))])
+    np.testing.assert_allclose(x, exp_x, rtol=0, atol=2e-5)      # 16 ns x float32 epsilon of the fraction
+    np.testing.assert_allclose(xh, exp_h, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(xt, exp_h - exp_x, rtol=0, atol=4e-5)
+
+
 def test_multi_intersect_reference_values():      # test/test_multiintersect.jl:7-27
     y = np.arange(1.0, 101.0)
     w = wv(y, 1.0, 1.0)
