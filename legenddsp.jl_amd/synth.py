@@ -4,6 +4,13 @@ image.  Shapes follow the reference's own fixtures: `make_fake_waveform`
 (reference test/test_dsp_sipm.jl:10-26), with per-trace randomised baseline,
 amplitude, onset, rise time and Gaussian noise.  Generated with torch so the
 same code fills host memory (CPU tests) or HBM (bench) directly.
+
+Counter-based: every random number is a hash of (seed, stream, global trace index, sample index) — SplitMix64's
+finaliser over a 64-bit counter, in torch int64 arithmetic (which wraps) — so trace i of a batch is the same whatever
+the batch it is generated in: `hpge_batch(n, first_trace=k)` IS rows k .. k+n-1 of the whole job's batch, for any k and any
+chunking (a rank of the multi-GPU bench generates exactly its shard; a test can regenerate any row of the 1 M-trace batch).
+The integer part is bit-identical on CPU and GPU; the float32 logarithm / cosine of the Gaussian transform may differ in the
+last place between the two.
 """
 import math
 
@@ -32,9 +39,56 @@ def reference_sipm_waveform(n=6250, dtype=torch.float64):
     return sig.to(dtype)
 
 
-def hpge_batch(n, L=8192, seed=0x1E6E4D, device="cpu", noise=3.0, chunk=65536, out=None, first_trace=0):
+_M64 = (1 << 64) - 1
+
+
+def _s64(v):
+    """Python int -> the same 64 bits as a signed int64 value."""
+    v &= _M64
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+_GOLD, _MIX1, _MIX2, _STREAM = _s64(0x9E3779B97F4A7C15), _s64(0xBF58476D1CE4E5B9), _s64(0x94D049BB133111EB), 0xD1342543DE82EF95
+
+
+def _lsr(z, k):
+    return (z >> k) & ((1 << (64 - k)) - 1)      # logical shift right of an int64 tensor
+
+
+def _hash_u24(counter, seed, stream):
+    """SplitMix64 finaliser of `counter` (int64 tensor) keyed by (seed, stream) -> 24 random bits per element (int64 tensor)."""
+    z = counter * _GOLD + _s64(seed * 0x2545F4914F6CDD1D + (stream + 1) * _STREAM)
+    z = (z ^ _lsr(z, 30)) * _MIX1
+    z = (z ^ _lsr(z, 27)) * _MIX2
+    z = z ^ _lsr(z, 31)
+    return _lsr(z, 40)
+
+
+def _uniform(counter, seed, stream):
+    """U(0, 1) float32, never 0 or 1."""
+    return (_hash_u24(counter, seed, stream).to(torch.float32) + 0.5) * (1.0 / 16777216.0)
+
+
+def _normal_into(out, first_counter, seed, stream):
+    """Fill `out` [m, L] (float32) with N(0, 1): element (i, j) from the counter first_counter + i * L + j (Box-Muller on two
+    uniforms of that counter)."""
+    m, L = out.shape
+    c = torch.arange(m * L, device=out.device, dtype=torch.int64).view(m, L) + int(first_counter)
+    u1 = _uniform(c, seed, stream)
+    u2 = _uniform(c, seed, stream + 1)
+    del c
+    torch.log(u1, out=u1)
+    u1.mul_(-2.0).sqrt_()
+    u2.mul_(2.0 * math.pi)
+    torch.cos(u2, out=u2)
+    torch.mul(u1, u2, out=out)
+    return out
+
+
+def hpge_batch(n, L=8192, seed=0x1E6E4D, device="cpu", noise=3.0, chunk=8192, out=None, first_trace=0):
     """x[i,j] = B + A*s(j-j0; R) + noise*g, float32.  B~U[900,1100], A~U[500,2e4],
-    j0~U{2950..3050}*L/8192, R~U{60..190}*L/8192, decay 31250*L/8192 samples."""
+    j0~U{2950..3050}*L/8192, R~U{60..190}*L/8192, decay 31250*L/8192 samples.  Row i is global trace first_trace + i
+    (counter-based, see the module text); `chunk` only bounds the temporaries."""
     dev = torch.device(device)
     if out is None:
         out = torch.empty((n, L), dtype=torch.float32, device=dev)
@@ -42,15 +96,14 @@ def hpge_batch(n, L=8192, seed=0x1E6E4D, device="cpu", noise=3.0, chunk=65536, o
     j = torch.arange(L, device=dev, dtype=torch.float32)[None, :]
     for c0 in range(0, n, chunk):
         c1 = min(n, c0 + chunk)
-        g = torch.Generator(device=dev)
-        g.manual_seed(seed + 7919 * ((first_trace + c0) // chunk))
         m = c1 - c0
-        B = 900 + 200 * torch.rand(m, 1, generator=g, device=dev)
-        A = 500 + 19500 * torch.rand(m, 1, generator=g, device=dev)
-        j0 = torch.floor((2950 + 101 * torch.rand(m, 1, generator=g, device=dev)) * sc)
-        R = torch.floor((60 + 131 * torch.rand(m, 1, generator=g, device=dev)) * sc).clamp_(min=1)
+        t = torch.arange(first_trace + c0, first_trace + c1, device=dev, dtype=torch.int64)[:, None]   # global trace index
+        B = 900 + 200 * _uniform(t, seed, 1)
+        A = 500 + 19500 * _uniform(t, seed, 2)
+        j0 = torch.floor((2950 + 101 * _uniform(t, seed, 3)) * sc)
+        R = torch.floor((60 + 131 * _uniform(t, seed, 4)) * sc).clamp_(min=1)
         x = out[c0:c1]
-        torch.randn((m, L), generator=g, device=dev, out=x)
+        _normal_into(x, (first_trace + c0) * L, seed, 8)
         x.mul_(noise)
         u = j - j0
         ramp = (u / R).clamp_(0, 1)
@@ -59,9 +112,23 @@ def hpge_batch(n, L=8192, seed=0x1E6E4D, device="cpu", noise=3.0, chunk=65536, o
     return out
 
 
-def sipm_batch(n, L=16384, seed=0x51B3, device="cpu", noise=0.3, mean_pulses=3.0, chunk=16384, out=None, first_trace=0):
+_POISSON3_CDF = None
+
+
+def _poisson_from_uniform(u, mean, kmax):
+    """Inverse-CDF Poisson(mean), clamped to kmax."""
+    cdf, p, acc = [], math.exp(-mean), 0.0
+    for k in range(kmax):
+        acc += p
+        cdf.append(acc)
+        p *= mean / (k + 1)
+    edges = torch.tensor(cdf, device=u.device, dtype=torch.float32)
+    return (u > edges[None, :]).sum(dim=1, keepdim=True).to(torch.float32)     # u: [m, 1] -> K: [m, 1]
+
+
+def sipm_batch(n, L=16384, seed=0x51B3, device="cpu", noise=0.3, mean_pulses=3.0, chunk=4096, out=None, first_trace=0):
     """K~Poisson(3) pulses of the reference SiPM shape (10-sample rise 1-exp(-k/3),
-    decay 30 samples), amplitudes U[2,10], uniform positions, N(0,0.3) noise."""
+    decay 30 samples), amplitudes U[2,10], uniform positions, N(0,0.3) noise.  Counter-based like `hpge_batch`."""
     dev = torch.device(device)
     if out is None:
         out = torch.empty((n, L), dtype=torch.float32, device=dev)
@@ -69,16 +136,17 @@ def sipm_batch(n, L=16384, seed=0x51B3, device="cpu", noise=0.3, mean_pulses=3.0
     j = torch.arange(L, device=dev, dtype=torch.float32)[None, :]
     for c0 in range(0, n, chunk):
         c1 = min(n, c0 + chunk)
-        g = torch.Generator(device=dev)
-        g.manual_seed(seed + 104729 * ((first_trace + c0) // chunk))
         m = c1 - c0
+        t = torch.arange(first_trace + c0, first_trace + c1, device=dev, dtype=torch.int64)[:, None]
         x = out[c0:c1]
-        torch.randn((m, L), generator=g, device=dev, out=x)
+        _normal_into(x, (first_trace + c0) * L, seed, 8)
         x.mul_(noise)
-        K = torch.poisson(torch.full((m, 1), mean_pulses, device=dev), generator=g).clamp_(max=kmax)
+        K = _poisson_from_uniform(_uniform(t, seed, 1), mean_pulses, kmax)
         for k in range(kmax):
-            pos = torch.floor(64 + (L - 256) * torch.rand(m, 1, generator=g, device=dev))
-            amp = (2 + 8 * torch.rand(m, 1, generator=g, device=dev)) * (K > k)
+            pos = torch.floor(64 + (L - 256) * _uniform(t, seed, 16 + 2 * k))
+            amp = (2 + 8 * _uniform(t, seed, 17 + 2 * k)) * (K > k)
+            if not bool((amp > 0).any()):
+                continue
             u = j - pos
             rise = (1 - torch.exp(-u.clamp(min=0) / 3.0)) * ((u >= 0) & (u < 10))
             fall = torch.exp(-(u - 10).clamp(min=0) / 30.0) * (u >= 10)

@@ -98,7 +98,9 @@ def sipm_compare(sc, trig, ora, n):
         diff = int((cg != co).sum())
         same = cg == co
         xa, xb = trig[g]["x"].cpu().numpy().astype(np.float64), ora[g]["x"]
-        okx = (np.abs(xa - xb) <= 0.05) | (np.isnan(xa) & np.isnan(xb))
+        # ns.  The discharge groups cross a threshold on the INTEGRATED signal (a float32 running sum in the kernel, float64 in the
+        # oracle): a shallow crossing moves by dt * (4e-6 |I|) / slope — measured up to 0.052 ns (tools/sipm_diag.py)
+        okx = (np.abs(xa - xb) <= (0.1 if "DC" in g else 0.05)) | (np.isnan(xa) & np.isnan(xb))
         xbad = int((~okx[same]).any(axis=1).sum())
         if diff or xbad:
             msgs.append(f"{g}: count differs on {diff}, positions on {xbad} of {n} (mean count {co.mean():.1f})")

@@ -169,7 +169,7 @@ def test_multi_intersect_matches_oracle_on_hpge_traces(orc, batch, mintot_sample
     ora = _multi_oracle(orc, x, ratios, mintot_samples, half_n, degree, rate)
     assert all(o is not None for o in ora)
     ora = np.stack(ora)
-    bad = ~(np.abs(got - ora) <= 0.02 * DT)            # 0.02 sample: float32 interpolation of a noisy edge
+    bad = ~((np.abs(got - ora) <= 0.02 * DT) | (np.isnan(got) & np.isnan(ora)))   # 0.02 sample: float32 interpolation of a noisy edge; NaN on both sides = a threshold that is never confirmed
     assert bad.sum() == 0, (np.argwhere(bad)[:10], got[bad][:10], ora[bad][:10])
     ctx = ldsp.default_context(batch.signal.device.index)
     ctx.set_option("multi_serial", 1)
@@ -177,7 +177,7 @@ def test_multi_intersect_matches_oracle_on_hpge_traces(orc, batch, mintot_sample
         serial = host(f(batch))
     finally:
         ctx.set_option("multi_serial", 0)
-    assert np.array_equal(serial, host(f(batch)))
+    assert np.array_equal(serial, host(f(batch)), equal_nan=True)
 
 
 def test_multi_intersect_hard_traces_and_window_status(orc):

@@ -132,6 +132,7 @@ def test_sipm_quantised_and_degenerate_traces(orc):
     wf[13] = 100.0 * wf[13]                         # almost everything outside the MAD windows
     ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=8)
     ctx = ldsp.default_context()
+    thr_of = {}
     for generic in (0, 1):
         ctx.set_option("sipm_generic", generic)
         sc, trig = ldsp.sipm_run(wf, p, ctx)
@@ -140,9 +141,17 @@ def test_sipm_quantised_and_degenerate_traces(orc):
         for c in ("threshold", "threshold_DC", "threshold_trap", "threshold_DC_trap"):
             i = ldsp._abi.SIPM_SCALAR_COLS.index(c)
             a, b = sc[i].cpu().numpy().astype(np.float64), ora[c]
-            ok = (np.abs(a - b) <= 2e-3 + 1e-4 * np.abs(b)) | (np.isnan(a) & np.isnan(b))
+            tol = 2e-3 + 1e-4 * np.abs(b)
+            # row 13 (trace x 100): few samples are left inside the MAD window, neighbouring order statistics lie ~1e-2 apart, and
+            # ONE sample whose float32 value falls on the other side of the window bound than its float64 value moves the median
+            # by such a gap (the two kernels — different selection algorithms — agree with each other, checked below)
+            tol[13] = 1e-2 * np.abs(b[13])
+            ok = (np.abs(a - b) <= tol) | (np.isnan(a) & np.isnan(b))
             assert ok.all(), (generic, c, a[~ok], b[~ok])
+            thr_of.setdefault(c, []).append(a)
     ctx.set_option("sipm_generic", 0)
+    for c, (a0, a1) in thr_of.items():
+        np.testing.assert_allclose(a0[13], a1[13], rtol=1e-6, err_msg=c)
 
 
 @pytest.mark.parametrize("generic", [0, 1])
