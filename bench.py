@@ -166,10 +166,10 @@ def timed(env, args, step, finish=lambda: None):
 # Compute-issue ceilings of the full dsp_icpc chain at L = 8192 (waveforms/s per GPU):
 #   "algorithmic": the minimum arithmetic of the restructured chain (~85 VALU operations per sample) at the measured issue costs
 #   (profiles/r03_micro_issue_costs.txt), perfectly packed, no LDS or barrier time;
-#   "instruction_stream": the instructions icpc_lean3_kernel actually issues — 3 690 VALU per wave of 16 samples per lane
-#   (profiles/r03_lean3_phase_insts.txt), of which 46 % are moves / selects / compares / DPP (profiles/r03_lean3_valu_mix.txt) —
-#   priced per class at those costs: ~12 k VALU-pipe cycles per wave, 8 waves per trace, 1 024 SIMDs at 2.4 GHz.
-ISSUE_CEILING_ICPC = {"algorithmic": 65.0e6, "instruction_stream": 25.6e6}
+#   "instruction_stream": the VALU time of the instructions icpc_lean3_kernel actually issues, from the hardware counter:
+#   SQ_ACTIVE_INST_VALU = 3 747 quad-cycles per wave (profiles/r03_lean3_valu_mix.txt; 3 690 instructions at 4.07 cycles on average —
+#   46 % of them moves / selects / compares / DPP), 8 waves per trace, 1 024 SIMDs at 2.4 GHz: 2.4e9 * 1024 / (8 * 3747 * 4).
+ISSUE_CEILING_ICPC = {"algorithmic": 65.0e6, "instruction_stream": 20.5e6}
 
 
 def roofline(achieved_gbs, kernel, kernel_ms, bytes_per_trace, traffic, issue_of=None):
