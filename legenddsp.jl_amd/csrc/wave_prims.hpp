@@ -175,67 +175,77 @@ __device__ __forceinline__ void put_ballots(uint32_t& acc, unsigned long long a,
 // register).  With three or more chains the two wait states a DPP read needs after a VALU write of the same VGPR are filled by
 // the other chains; one or two chains keep an s_nop in every step.  After the last step lane 63 holds the wave total /
 // maximum / minimum and lane l the inclusive scan (sums).
-#define LDSP_DPP_GROUP1(O0, v0) do { \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0)); \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0)); \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0)); \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0)); \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0)); \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0)); \
-} while (0)
-#define LDSP_DPP_GROUP2(O0, v0, O1, v1) do { \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1)); \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1)); \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1)); \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1)); \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1)); \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1)); \
-} while (0)
-#define LDSP_DPP_GROUP3(O0, v0, O1, v1, O2, v2) do { \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2)); \
-  asm volatile(O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2)); \
-  asm volatile(O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2)); \
-} while (0)
-#define LDSP_DPP_GROUP4(O0, v0, O1, v1, O2, v2, O3, v3) do { \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)); \
-  asm volatile(O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)); \
-  asm volatile(O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)); \
-} while (0)
-#define LDSP_DPP_GROUP5(O0, v0, O1, v1, O2, v2, O3, v3, O4, v4) do { \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4)); \
-  asm volatile(O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4)); \
-  asm volatile(O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4)); \
-} while (0)
-#define LDSP_DPP_GROUP6(O0, v0, O1, v1, O2, v2, O3, v3, O4, v4, O5, v5) do { \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5)); \
-  asm volatile(O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5)); \
-  asm volatile(O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5)); \
-} while (0)
-#define LDSP_DPP_GROUP7(O0, v0, O1, v1, O2, v2, O3, v3, O4, v4, O5, v5, O6, v6) do { \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6)); \
-  asm volatile(O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6)); \
-  asm volatile(O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6)); \
-} while (0)
-#define LDSP_DPP_GROUP8(O0, v0, O1, v1, O2, v2, O3, v3, O4, v4, O5, v5, O6, v6, O7, v7) do { \
-  asm volatile("s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)); \
-  asm volatile(O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)); \
-  asm volatile(O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)); \
-  asm volatile(O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7)); \
-} while (0)
+// (generated: ONE asm statement per group — all six steps — so that neither the scheduler nor the register allocator can put a
+// copy or a reload between a step's write and the next step's DPP read; the hazard recogniser does not look inside inline asm)
+#define LDSP_DPP_GROUP1(O0, v0) \
+  asm volatile( \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" \
+    : "+v"(v0))
+#define LDSP_DPP_GROUP2(O0, v0, O1, v1) \
+  asm volatile( \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" \
+    "s_nop 0\n\t" O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" \
+    "s_nop 0\n\t" O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" \
+    "s_nop 0\n\t" O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" \
+    "s_nop 0\n\t" O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" \
+    "s_nop 0\n\t" O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" \
+    : "+v"(v0), "+v"(v1))
+#define LDSP_DPP_GROUP3(O0, v0, O1, v1, O2, v2) \
+  asm volatile( \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" \
+    : "+v"(v0), "+v"(v1), "+v"(v2))
+#define LDSP_DPP_GROUP4(O0, v0, O1, v1, O2, v2, O3, v3) \
+  asm volatile( \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" \
+    : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3))
+#define LDSP_DPP_GROUP5(O0, v0, O1, v1, O2, v2, O3, v3, O4, v4) \
+  asm volatile( \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf" \
+    : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4))
+#define LDSP_DPP_GROUP6(O0, v0, O1, v1, O2, v2, O3, v3, O4, v4, O5, v5) \
+  asm volatile( \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf" \
+    : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5))
+#define LDSP_DPP_GROUP7(O0, v0, O1, v1, O2, v2, O3, v3, O4, v4, O5, v5, O6, v6) \
+  asm volatile( \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf" \
+    : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6))
+#define LDSP_DPP_GROUP8(O0, v0, O1, v1, O2, v2, O3, v3, O4, v4, O5, v5, O6, v6, O7, v7) \
+  asm volatile( \
+    "s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t" \
+    O0 " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O1 " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O2 " %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O3 " %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O4 " %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O5 " %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O6 " %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf" "\n\t" O7 " %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf" \
+    : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7))

@@ -51,6 +51,24 @@ def test_icpc_matches_oracle_seeded_batch(orc, params, direct, generic):
     assert worst <= parity.FLIP_FRAC, "\n".join(lines)
 
 
+def test_lean_and_generic_kernels_agree(params):
+    """The two implementations of the chain (icpc_lean3_kernel: pivoted sums, one exchange; icpc_kernel: the round-1 form) against
+    EACH OTHER on the seeded batch, tighter than either is held to the oracle: a regression in the run-count or mask logic of one
+    of them shows here even where the oracle budget (inTrace_n within 3, parity.py) would let it pass.  Integer columns equal on
+    every row but threshold-decision flips (each kernel rounds its own sigma): at most 1 % of rows, and then by one count."""
+    n = 512
+    wf = ldsp.synth.hpge_batch(n, L, device="cuda", seed=7)
+    lean, gen = _run(wf, params, 0, 0), _run(wf, params, 0, 1)
+    for c in parity.INT_COLS:
+        a, b = lean[c].astype(np.int64), gen[c].astype(np.int64)
+        diff = a != b
+        assert diff.sum() <= n // 100, (c, int(diff.sum()))
+        assert np.abs(a - b).max() <= 1, (c, a[diff][:8], b[diff][:8])
+    for c, tol in (("blmean", 2e-4), ("e_max", 2e-3), ("e_10410", 0.02), ("e_trap", 0.02), ("e_cusp", 0.05), ("e_zac", 0.05), ("t50", 2e-5), ("t0", 2e-5)):
+        d = np.abs(lean[c].astype(np.float64) - gen[c].astype(np.float64))
+        assert (d > tol).sum() <= n // 100, (c, float(np.nanmax(d)))
+
+
 def test_float32_envelope(orc, params):
     """The Float32-typed restatement (oracle/ldsp_oracle.c -DORC_F32: what the reference computes for Float32 input) against the
     Float64 one on the seeded batch: printed per column next to the HIP path's error (tests/parity.py, module text).  The HIP
