@@ -10,7 +10,7 @@ import legenddsp_jl_amd as ldsp
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and "=" not in sys.argv[1] else 65536
 opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a and not a.startswith("base:"))
-BASE_OPTS = dict(a[5:].split("=") for a in sys.argv[1:] if a.startswith("base:"))   # options set in both runs, e.g. base:icpc_lean3=1
+BASE_OPTS = dict(a[5:].split("=") for a in sys.argv[1:] if a.startswith("base:"))   # options set in both runs, e.g. base:icpc_generic=1
 L = 8192
 p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * ldsp.us, {}, L, 0.0, 16.0)
 wf = ldsp.synth.hpge_batch(n, L, device="cuda")
