@@ -486,11 +486,14 @@ def run_rank(args):
                 del wf
                 env.torch.cuda.empty_cache()
                 sec.append(bench_sipm(env, args, 625_000, 16384))         # BASELINE config 5's single-GPU shard
-                # parameter sets that do NOT take the kernel above: a trace length that does not fill the tile ->
-                # icpc_kernel (the generic kernel); CUSP and ZAC optimised separately (pars_filter) -> the two-pass instantiation
+                # parameter sets beside the headline's: a trace shorter than the tile -> the bounded instantiation;
+                # a length that is no multiple of four samples -> icpc_kernel (the generic kernel: what leaving the lean kernel costs);
+                # CUSP and ZAC optimised separately (pars_filter) -> the two-pass instantiation
                 import legenddsp_jl_amd as ldsp
                 us = ldsp.us
-                r_gen, _ = bench_icpc(env, args, 262_144, 8000, "icpc", label="fallback: 262144 x 8000 f32 (the trace does not fill the tile -> generic icpc_kernel)")
+                r_short, _ = bench_icpc(env, args, 262_144, 8000, "icpc", label="262144 x 8000 f32: a trace shorter than the tile (8192) -> the bounded instantiation of the same kernel")
+                sec.append(r_short)
+                r_gen, _ = bench_icpc(env, args, 262_144, 8190, "icpc", label="fallback: 262144 x 8190 f32 (rows that are not 16-byte aligned -> generic icpc_kernel)")
                 sec.append(r_gen)
                 r_sep, _ = bench_icpc(env, args, 262_144, 8192, "icpc", pars_filter={"cusp": {"rt": 4.0 * us, "ft": 1.5 * us}, "zac": {"rt": 5.5 * us, "ft": 2.0 * us}},
                                       label="262144 x 8192 f32, CUSP and ZAC optimised separately (pars_filter): two passes of the closed-form stage in one launch")

@@ -303,16 +303,26 @@ __device__ __forceinline__ uint32_t nib_le(f4 v, float t) {
 #ifndef LDSP_L3_WPS
 #define LDSP_L3_WPS 6
 #endif
+#ifndef LDSP_L3_RWPS   // the same for traces shorter than the tile (their bounds cost registers)
+#define LDSP_L3_RWPS 6
+#endif
 // SEP: CUSP and ZAC have their own geometry (two passes of the closed-form stage); keeps a second copy of y in registers
-template <int NT, int M, bool SEP>
-__global__ void __launch_bounds__(NT, SEP ? 4 : LDSP_L3_WPS)
+// FULL: the trace fills the tile (L = 16 NT) — the production geometry, no bounds anywhere; !FULL: a shorter trace (L % 4 == 0)
+template <int NT, int M, bool SEP, bool FULL>
+__global__ void __launch_bounds__(NT, SEP ? 4 : (NT == 64 ? 5 : (FULL ? LDSP_L3_WPS : LDSP_L3_RWPS)))   // (one-wave workgroups: 96 registers)
 icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOutDev out, const float* __restrict__ ext_bl,
                   float ext_bl_scale) {
   using SM = Smem<NT>;
-  constexpr int NW = SM::NW, Lp = SM::Lp, NWORDS = SM::NWORDS, L = Lp;
+  constexpr int NW = SM::NW, Lp = SM::Lp, NWORDS = SM::NWORDS;
   static_assert(R * NW <= 64, "wave-row partials must fit one wave");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const IcpcDev& P = *Pp;
+  // Trace length: the tile (Lp = 16 NT samples) or less (L % 4 == 0, the host admits nothing else).  Lanes whose quad lies beyond
+  // L load the trace's last quad once more: real sample values, so the raw extremes are unchanged; every filter of the chain is
+  // causal up to its own output range, every output range is bounded by L below (nout, ng, the crossing tests), and the one
+  // anti-causal recursion (CUSP / ZAC) runs on a difference signal that is set to zero beyond L.
+  const int L = FULL ? Lp : P.L;
+  auto in_trace = [&](int i4) { return FULL ? i4 : min(i4, L - 4); };   // offset of a quad, or of the last one
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Lf_max = max(P.cusp.Lf, P.zac.Lf);
@@ -333,12 +343,12 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   if (P.in_u16) {   // (block-uniform)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint2 q = *reinterpret_cast<const uint2*>(w16 + 4 * (tid + NT * r));
+      const uint2 q = *reinterpret_cast<const uint2*>(w16 + in_trace(4 * (tid + NT * r)));
       x[r] = (f4){(float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16)};
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
+    for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const f4*>(w + in_trace(4 * (tid + NT * r)));
   }
   const float pv_bl = wv(P.bl.from);      // pivot of the baseline sums: the window's first sample
   for (int i = tid; i < 2 * EST_TBL; i += NT)   // LSQ basis tables of the two estimators -> LDS
@@ -455,12 +465,14 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         f4 v;
+        const int i0 = 4 * (tid + NT * r);
         if (P.in_u16) {
-          const uint2 q = *reinterpret_cast<const uint2*>(w16 + 4 * (tid + NT * r));
+          const uint2 q = *reinterpret_cast<const uint2*>(w16 + in_trace(i0));
           v = (f4){(float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16)};
         } else {
-          v = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
+          v = *reinterpret_cast<const f4*>(w + in_trace(i0));
         }
+        if (!FULL && i0 >= L) v = (f4){NAN, NAN, NAN, NAN};   // beyond the trace: equal to neither rail
         n_low += (v.x == lo_) + (v.y == lo_) + (v.z == lo_) + (v.w == lo_);
         n_high += (v.x == hi_) + (v.y == hi_) + (v.z == hi_) + (v.w == hi_);
         *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = v;
@@ -565,7 +577,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (tid == 0) S.X[Lp] = S.misc[16] + (S.misc[17] - delta * ((float)L * fmaf(hc, (float)(L + 1), 1.f)));   // T[L]
+    if (tid == 0) S.X[Lp] = S.misc[16] + (S.misc[17] - delta * ((float)Lp * fmaf(hc, (float)(Lp + 1), 1.f)));   // T[Lp] (a full tile's T[L]; a shorter trace has its T[L] at X[L])
   }
   auto& y = x;
   // get_threshold at 10 / 50 / 80 / 90 / 99 % of the pre-PZ maximum (dsp_icpc.jl:132-136): first quad of this wave reaching
@@ -1006,7 +1018,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       __syncthreads();
       if (tid < 5) S.sl->imin[IM_TX0 + tid] = 0x7fffffff;
       for (int m = 0; m < SP; ++m) {
-        const float yv = S.X[tid + NT * m];
+        const float yv = (FULL || tid + NT * m < L) ? S.X[tid + NT * m] : -INFINITY;   // (nothing beyond the trace crosses)
 #pragma unroll
         for (int qq = 0; qq < 5; ++qq) {
           const unsigned long long b = __ballot(yv >= e_maxl * ((qq == 0) ? 0.1f : (qq == 1) ? 0.5f : (qq == 2) ? 0.8f : (qq == 3) ? 0.9f : 0.99f));
@@ -1439,6 +1451,9 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       d[r][1].x = fmaf(Z.eps, y[r].y, (y[r].z - y[r].y) + mec);
       d[r][1].y = fmaf(Z.eps, y[r].z, (y[r].w - y[r].z) + mec);
       if (r == 0 && tid == 0) d[0][0].x = 0.f;
+      if (!FULL && 4 * NT * (r + 1) > L) {   // (block-uniform) a row that reaches beyond the trace: d = 0 there
+        if (4 * (opaque(tid) + NT * r) >= L) { d[r][0] = splat(0.f); d[r][1] = splat(0.f); }
+      }
     }
     STAMP(19); DSTOP(19);
     const float q1 = Z.qp1[1];
@@ -1601,13 +1616,13 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   }
 }
 
-template <int NT, int M, bool SEP>
+template <int NT, int M, bool SEP, bool FULL>
 static hipError_t launch_t(const float* wf, int64_t n, const IcpcDev* dP, const IcpcOutDev& out, const float* ext_bl, float ext_bl_scale,
                            int Lf, hipStream_t st) {
   const size_t smem = Smem<NT>::bytes(cz_pad_floats(Lf)) + (size_t)g_dbg_lds_pad;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_lean3_kernel<NT, M, SEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_lean3_kernel<NT, M, SEP, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((icpc_lean3_kernel<NT, M, SEP>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, out, ext_bl, ext_bl_scale);
+  hipLaunchKernelGGL((icpc_lean3_kernel<NT, M, SEP, FULL>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, out, ext_bl, ext_bl_scale);
   return hipGetLastError();
 }
 
@@ -1625,21 +1640,27 @@ size_t icpc_lean3_smem_bytes(int NT, int Lf) {
 }
 
 // sg_slots: 7 or 13 (the smallest that holds the three Savitzky-Golay windows)
-hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, const IcpcDev* dP, const IcpcOutDev& out,
+// full: the traces fill the tile (L = 16 NT); shorter traces (L % 4 == 0) only with shared CUSP / ZAC geometry
+hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, bool full, const IcpcDev* dP, const IcpcOutDev& out,
                              const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st) {
+  if (!full && !cz_shared) return hipErrorInvalidValue;
 #ifdef LDSP_DEV_512
 #define LDSP_LEAN_CASES LDSP_CASE(512)
 #else
 #define LDSP_LEAN_CASES LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512)
 #endif
+#define LDSP_ARGS wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st
 #define LDSP_CASE(N) \
-  case N: return cz_shared ? (sg_slots <= 7 ? lean3::launch_t<N, 7, false>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st) : lean3::launch_t<N, 13, false>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st)) \
-                           : (sg_slots <= 7 ? lean3::launch_t<N, 7, true>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st) : lean3::launch_t<N, 13, true>(wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st));
+  case N: \
+    if (!full) return sg_slots <= 7 ? lean3::launch_t<N, 7, false, false>(LDSP_ARGS) : lean3::launch_t<N, 13, false, false>(LDSP_ARGS); \
+    return cz_shared ? (sg_slots <= 7 ? lean3::launch_t<N, 7, false, true>(LDSP_ARGS) : lean3::launch_t<N, 13, false, true>(LDSP_ARGS)) \
+                     : (sg_slots <= 7 ? lean3::launch_t<N, 7, true, true>(LDSP_ARGS) : lean3::launch_t<N, 13, true, true>(LDSP_ARGS));
   switch (NT) {
     LDSP_LEAN_CASES
     default: return hipErrorInvalidValue;
   }
 #undef LDSP_CASE
+#undef LDSP_ARGS
 }
 
 }  // namespace ldsp

@@ -19,7 +19,7 @@ namespace ldsp {
 hipError_t launch_icpc(const float* wf, int64_t n, int NT, int R, bool full, const IcpcDev* dP, float* aux, const IcpcOutDev& out,
                        const float* ext_bl, float ext_bl_scale, bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid,
                        int* stages);
-hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, const IcpcDev* dP, const IcpcOutDev& out,
+hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, bool full, const IcpcDev* dP, const IcpcOutDev& out,
                              const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st);
 size_t icpc_lean3_smem_bytes(int NT, int Lf);
 extern int g_dbg_lds_pad;
@@ -447,10 +447,13 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, int r2, Ic
 // eps * T term of the filters' last tap, which icpc_lean3 drops, is far below the columns' resolution: |w_last| * eps * rail * L
 // < 1e-2 on a trace that sits at the rail, a hundredth of that on a real one (dsp_icpc sets the filters' tau to 1e7 us,
 // src/dsp_icpc.jl:98: 1.4e-3 for a 16-bit rail and 8192 samples).  ldsp_icpc_run and ldsp_icpc_pz_trap_run decide alike.
-static bool icpc_lean_applies(const ldsp_ctx* c) {
+// `full_tile`: only traces that fill the tile (config 2's lean kernel); the fused kernel also takes shorter traces whose length is a
+// multiple of four samples (16-byte rows: quads are loaded whole) — 8000-, 7300-, 6000-sample traces run it on the next tile up.
+static bool icpc_lean_applies(const ldsp_ctx* c, bool full_tile = false) {
   const IcpcDev& H = c->icpc_host;
   const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
-  if (c->icpc_generic || c->two_kernel || !(c->dbg_stop == 0 || c->dbg_stop >= 100) || H.R != 4 || H.L != 16 * H.NT || H.NT > 512 ||
+  if (c->icpc_generic || c->two_kernel || !(c->dbg_stop == 0 || c->dbg_stop >= 100) || H.R != 4 || H.L > 16 * H.NT || H.NT > 512 ||
+      (H.L & 3) != 0 || H.L < 64 || ((full_tile || !H.cz_shared) && H.L != 16 * H.NT) ||
       H.cusp_mode != 1 || !H.t0inv_same || H.tx_mintot > 2 || sg_max > 13)
     return false;
   const double rail = std::max(std::fabs((double)H.sat_high), std::fabs((double)H.sat_low)) * (double)H.L;
@@ -527,7 +530,7 @@ int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_
   const IcpcDev& H = c->icpc_host;
   const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
   if (icpc_lean_applies(c) && !main_only) {
-    HIP_TRY(launch_icpc_lean3(wf, n, H.NT, sg_max, H.cz_shared != 0, c->d_icpc, od, ext_bl, ext_bl_scale, std::max(H.cusp.Lf, H.zac.Lf), c->stream));
+    HIP_TRY(launch_icpc_lean3(wf, n, H.NT, sg_max, H.cz_shared != 0, H.L == 16 * H.NT, c->d_icpc, od, ext_bl, ext_bl_scale, std::max(H.cusp.Lf, H.zac.Lf), c->stream));
     c->last_kernel = "lean3::icpc_lean3_kernel";
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
     return LDSP_OK;
@@ -552,7 +555,7 @@ static int pz_trap_run_impl(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_
   if (rc) return rc;
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   const int nt_pz = c->icpc_host.R == 2 ? 512 : c->icpc_host.NT;   // pz_trap_kernel keeps 16 samples per thread
-  if (icpc_lean_applies(c)) {
+  if (icpc_lean_applies(c, true)) {
     HIP_TRY(launch_pz_trap_lean(wf, n, c->icpc_host.NT, in_u16, c->d_icpc, blmean, e_10410, c->stream));
     c->last_kernel = "lean::pz_trap_lean_kernel";
   } else {

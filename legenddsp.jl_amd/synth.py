@@ -85,7 +85,13 @@ def _normal_into(out, first_counter, seed, stream):
     return out
 
 
-def hpge_batch(n, L=8192, seed=0x1E6E4D, device="cpu", noise=3.0, chunk=8192, out=None, first_trace=0):
+def _chunk(chunk, dev, L):
+    """Traces per pass: `chunk` bounds the temporaries only (the values do not depend on it).  Default: 2^26 samples per pass on
+    the host, 2^29 on a GPU (a few 4 GB int64 temporaries; fewer, larger kernels)."""
+    return int(chunk) if chunk else max(1, ((1 << 29) if dev.type == "cuda" else (1 << 26)) // L)
+
+
+def hpge_batch(n, L=8192, seed=0x1E6E4D, device="cpu", noise=3.0, chunk=None, out=None, first_trace=0):
     """x[i,j] = B + A*s(j-j0; R) + noise*g, float32.  B~U[900,1100], A~U[500,2e4],
     j0~U{2950..3050}*L/8192, R~U{60..190}*L/8192, decay 31250*L/8192 samples.  Row i is global trace first_trace + i
     (counter-based, see the module text); `chunk` only bounds the temporaries."""
@@ -93,6 +99,7 @@ def hpge_batch(n, L=8192, seed=0x1E6E4D, device="cpu", noise=3.0, chunk=8192, ou
     if out is None:
         out = torch.empty((n, L), dtype=torch.float32, device=dev)
     sc = L / 8192.0
+    chunk = _chunk(chunk, dev, L)
     j = torch.arange(L, device=dev, dtype=torch.float32)[None, :]
     for c0 in range(0, n, chunk):
         c1 = min(n, c0 + chunk)
@@ -126,13 +133,14 @@ def _poisson_from_uniform(u, mean, kmax):
     return (u > edges[None, :]).sum(dim=1, keepdim=True).to(torch.float32)     # u: [m, 1] -> K: [m, 1]
 
 
-def sipm_batch(n, L=16384, seed=0x51B3, device="cpu", noise=0.3, mean_pulses=3.0, chunk=4096, out=None, first_trace=0):
+def sipm_batch(n, L=16384, seed=0x51B3, device="cpu", noise=0.3, mean_pulses=3.0, chunk=None, out=None, first_trace=0):
     """K~Poisson(3) pulses of the reference SiPM shape (10-sample rise 1-exp(-k/3),
     decay 30 samples), amplitudes U[2,10], uniform positions, N(0,0.3) noise.  Counter-based like `hpge_batch`."""
     dev = torch.device(device)
     if out is None:
         out = torch.empty((n, L), dtype=torch.float32, device=dev)
     kmax = 12
+    chunk = _chunk(chunk, dev, L)
     j = torch.arange(L, device=dev, dtype=torch.float32)[None, :]
     for c0 in range(0, n, chunk):
         c1 = min(n, c0 + chunk)

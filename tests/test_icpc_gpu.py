@@ -257,6 +257,46 @@ def test_threshold_crossings_with_spikes_before_the_pulse(orc, params):
         # the spikes did what they were meant to: traces 0..15 keep their crossing at the pulse, 16..23 moved to the spike pair
         assert np.all(gpu["t10"][:16] > 40.0) and np.all(gpu["t10"][16:24] < 20.0)
 
+@pytest.mark.parametrize("length,kernel", [(8000, "lean3::icpc_lean3_kernel"), (7300, "lean3::icpc_lean3_kernel"), (4400, "lean3::icpc_lean3_kernel"),
+                                            (8190, "icpc_kernel"), (7301, "icpc_kernel")])
+def test_traces_shorter_than_the_tile(orc, length, kernel):
+    """A trace that does not fill the tile (16 x threads samples) still runs the fused lean kernel when its rows are 16-byte
+    aligned (length % 4 == 0: quads are loaded whole; the lanes beyond the trace load its last quad again and every output range
+    is bounded by the length) — 8000-, 7300-, 4400-sample traces; other lengths run icpc_kernel.  Both against the oracle on
+    traces whose pulse, tail and windows reach to the very end of the trace, and the lean kernel against the generic one."""
+    sc = length / 8192.0
+    dt = 16.0
+    us = ldsp.us
+    import dataclasses
+    cfg = dataclasses.replace(ldsp.reference_test_icpc_config(),
+                              bl_window=ldsp.ClosedInterval(0.0, 39.0 * us * sc), tail_window=ldsp.ClosedInterval(70.0 * us * sc, (length - 1) * dt),
+                              current_window=ldsp.ClosedInterval(43.0 * us * sc, 62.0 * us * sc),
+                              flt_length_cusp=38.0 * us * sc, flt_length_zac=38.0 * us * sc)
+    p = ldsp.lower_icpc(cfg, 500 * us, {}, length, 0.0, dt)
+    n = 128
+    wf = ldsp.synth.hpge_batch(n, 8192, device="cuda", seed=61)
+    idx = (torch.arange(length, device="cuda", dtype=torch.float32) / sc).long().clamp(max=8191)
+    wf = wf[:, idx].contiguous()                     # the 8192-sample shapes resampled onto `length` samples
+    wf[:4, -3:] += 500.0                             # a step in the very last samples: nothing beyond the trace may answer it
+    host = wf.cpu().numpy()
+    ora = orc.dsp_icpc(host, p, nthreads=16)
+    ctx = ldsp.default_context()
+    gpu = _run(wf, p)
+    assert ctx.last_kernel_name() == kernel
+    lines, worst = parity.compare(gpu, ora, wf=host, params=p, orc=orc)
+    assert worst <= 2 / n, "\n".join(l for l in lines if f"bad=0/{n}" not in l)
+    if kernel.startswith("lean3"):
+        gen = _run(wf, p, generic=1)
+        assert ctx.last_kernel_name() == "icpc_kernel"
+        for c in parity.INT_COLS:
+            assert (np.abs(gpu[c].astype(np.int64) - gen[c].astype(np.int64)) > 0).sum() <= 2, c
+        # the saturation counters of a trace clipped at the rail in its last samples: the lanes beyond the trace count nothing
+        sat = wf.clone(); sat[:, -5:] = p.sat_high
+        a, b = _run(sat, p), _run(sat, p, generic=1)
+        for c in ("n_sat_high", "n_sat_high_cons", "n_sat_low", "n_sat_low_cons"):
+            assert np.array_equal(a[c], b[c]) and (c != "n_sat_high" or np.all(a[c] >= 5)), c
+
+
 def test_separately_optimised_cusp_and_zac_run_in_the_lean_launch(orc):
     """pars_filter with different rise / flat-top times for CUSP and ZAC (what an optimisation campaign produces): the lean
     kernel evaluates the two filters in two passes of its closed-form stage inside the SAME launch (y kept in registers for
@@ -297,7 +337,7 @@ def test_uint16_adc_counts_are_converted_by_the_kernel(params, generic, two_kern
 @pytest.mark.parametrize("length,dt", [(8192, 16.0), (8000, 16.0), (4096, 32.0)])
 def test_pz_trap_subchain_on_uint16_adc_counts(length, dt):
     """ldsp_icpc_pz_trap_run_u16: uint16 ADC counts give blmean / e_10410 of the same values passed as float32, bit for bit
-    (lean kernel at 8192 and 4096 samples, generic kernel at 8000), and they are the fused chain's columns: blmean bit for bit;
+    (lean kernel at 8192 and 4096 samples, generic kernel at 8000), and they are the fused chain's columns: blmean bit for bit (8000: to the last bit, two kernels);
     e_10410 to the last bits (round 3: the fused chain takes T = prefix sum of the pole-zero output from ONE exchange of partial
     sums, config 2's kernel from two — the same sums in another order, each rounded once at the magnitude of T, 1e7..1e8)."""
     cfg = ldsp.plumbing_icpc_config_4096() if length == 4096 else ldsp.reference_test_icpc_config()
@@ -310,6 +350,9 @@ def test_pz_trap_subchain_on_uint16_adc_counts(length, dt):
     b = ldsp.icpc_pz_trap_run(wf16, p).cpu().numpy()
     assert np.array_equal(a, b)
     full = ldsp.table_columns(ldsp.icpc_run(wf16, p))
-    assert np.array_equal(b[0], full["blmean"].cpu().numpy())
+    if length in (8192, 4096):      # the same statement in both lean kernels
+        assert np.array_equal(b[0], full["blmean"].cpu().numpy())
+    else:                           # 8000 samples: config 2 runs pz_trap_kernel, the fused chain icpc_lean3_kernel (shorter-than-tile traces)
+        np.testing.assert_allclose(b[0], full["blmean"].cpu().numpy(), rtol=2.5e-7)
     e_full = full["e_10410"].cpu().numpy().astype(np.float64)
     assert np.all(np.abs(b[1] - e_full) <= 0.02 + 3e-6 * np.abs(e_full)), np.abs(b[1] - e_full).max()

@@ -35,16 +35,27 @@ for t in ("gpu_time_grid", "gpu_time_compressed", "gpu_time_multi_intersect"):
     if os.path.exists(lg):
         with open(lg) as f, open(os.path.join(dst, f"{tag}_{t[9:]}_timing.txt"), "w") as g:
             g.write("".join(l for l in f if "amdgpu.ids" not in l and not l.startswith("[rocprofv3]") and "rocprofiler" not in l))
-# workloads of the bench command: kernel-name fragment -> (n_traces, L)
-# (the headline kernel is the shared-geometry instantiation <.., false>; the secondary dsp_icpc lines run the two-pass instantiation
-# <.., true> and the generic icpc_kernel)
-shapes = {"icpc_lean3_kernel": (bench["config"]["traces_per_gpu"], bench["config"]["samples"])}
+# workloads of the bench command: which (n_traces, L) a kernel of the PMC passes ran on.  icpc_lean3_kernel<NT, M, SEP, FULL>: the
+# headline is <.., false, true>; the secondary dsp_icpc lines run <.., true, true> (CUSP / ZAC optimised separately), <.., false, false>
+# (a trace shorter than the tile) and the generic icpc_kernel (a length the lean kernel does not take)
+shapes = {"headline": (bench["config"]["traces_per_gpu"], bench["config"]["samples"])}
 for sec in bench.get("secondary", []):
     shp = (sec["config"]["traces_per_gpu"], sec["config"]["samples"])
     if "pole-zero" in sec["metric"]: shapes["pz_trap"] = shp
     elif "dsp_sipm" in sec["metric"]: shapes["k_sipm"] = shp
-    elif "separately" in sec["config"]["workload"]: shapes["true>"] = shp
+    elif "separately" in sec["config"]["workload"]: shapes["sep"] = shp
     elif "fallback" in sec["config"]["workload"]: shapes["icpc_kernel<"] = shp
+    elif "shorter than the tile" in sec["config"]["workload"]: shapes["short"] = shp
+
+
+def shape_of(k):
+    if "icpc_lean3_kernel<" in k:
+        targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+        sep, full = targs[2] == "true", (len(targs) < 4 or targs[3] == "true")
+        return shapes.get("sep") if sep else shapes.get("headline") if full else shapes.get("short")
+    return next((sh for frag, sh in shapes.items() if frag in k and frag not in ("headline", "sep", "short")), None)
+
+
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for ctr, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     per_dispatch = collections.defaultdict(float)
@@ -56,7 +67,7 @@ for ctr, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         acc[names[k].replace("void ", "").split("(")[0]][ctr].append(v)
 recs = []
 for k, v in acc.items():
-    shape = shapes.get("true>") if ("icpc_lean3_kernel" in k and k.rstrip().endswith("true>")) else next((s for frag, s in shapes.items() if frag in k and frag != "true>"), None)
+    shape = shape_of(k)
     if shape is None or not v["FETCH_SIZE"] or not v["WRITE_SIZE"]:
         continue
     fa, wa = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])

@@ -13,14 +13,19 @@ python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | cut -c1-300
 rocprofv3 --kernel-trace --stats -d $O/stats -o p --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --cpu-sample 0 > $O/stats.log 2>&1
 echo "stats done"
-# HBM traffic: one pass per counter (MI355X_MICROARCH.md, HBM / rocprofv3 section), nothing else traced; counters only for the
-# library's own kernels (namespace ldsp): the thousands of small torch kernels that generate the synthetic input are not serialised
-rocprofv3 --kernel-trace --kernel-include-regex "ldsp" --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --kernel-include-regex "ldsp" --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/pmc_write.log 2>&1
+# HBM traffic: one pass per counter (MI355X_MICROARCH.md, HBM / rocprofv3 section), nothing else traced
+# (the synthetic input is generated in a few large passes on the GPU, legenddsp_jl_amd/synth.py: the counters serialise every kernel)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/pmc_write.log 2>&1
 echo "pmc done"
 for t in gpu_time_grid gpu_time_compressed gpu_time_multi_intersect; do
   rocprofv3 --kernel-trace --stats -d $O/stats_$t -o p --output-format csv -- python3 $R/tools/$t.py > $O/$t.log 2>&1 || echo "$t failed"
   grep -v amdgpu $O/$t.log | tail -12
 done
 rm -f $O/*/p_agent_info.csv
+# keep the rows of the library's own kernels only (the traces also list every torch kernel of the input generation)
+for f in $O/*/p_kernel_trace.csv $O/*/p_counter_collection.csv; do
+  [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep "ldsp::" "$f" >> "$f.tmp" || true; mv "$f.tmp" "$f"; }
+done
+du -sh $O
 ls $O
