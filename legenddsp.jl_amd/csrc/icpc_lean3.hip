@@ -340,15 +340,21 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   f4 x[R];
   const uint16_t* w16 = reinterpret_cast<const uint16_t*>(wf) + (size_t)blockIdx.x * (size_t)L;
   auto wv = [&](int i) { return P.in_u16 ? (float)w16[i] : w[i]; };
+  // (!FULL: the tile is the smallest that holds the trace, so rows 0 and 1 lie inside it; a lane whose quad of row 2 or 3 lies beyond
+  // the trace keeps a copy of its own row-0 quad there — real sample values: the raw extremes do not change)
   if (P.in_u16) {   // (block-uniform)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint2 q = *reinterpret_cast<const uint2*>(w16 + in_trace(4 * (tid + NT * r)));
+      if (!FULL && r >= 2) { x[r] = x[0]; if (4 * (tid + NT * r) >= L) continue; }
+      const uint2 q = *reinterpret_cast<const uint2*>(w16 + 4 * (tid + NT * r));
       x[r] = (f4){(float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16)};
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const f4*>(w + in_trace(4 * (tid + NT * r)));
+    for (int r = 0; r < R; ++r) {
+      if (!FULL && r >= 2) { x[r] = x[0]; if (4 * (tid + NT * r) >= L) continue; }
+      x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
+    }
   }
   const float pv_bl = wv(P.bl.from);      // pivot of the baseline sums: the window's first sample
   for (int i = tid; i < 2 * EST_TBL; i += NT)   // LSQ basis tables of the two estimators -> LDS
@@ -1445,6 +1451,8 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     for (int r = 0; r < R; ++r) {
       // (element by element: the odd-aligned pair (y1, y2) of a packed form is one the Savitzky-Golay pass also builds, and hipcc
       // then keeps that pass's copies alive — in scratch — until here)
+      if constexpr (!FULL)   // (keeps hipcc from carrying the sample differences of the Savitzky-Golay pass — in scratch — to this point)
+        asm volatile("" : "+v"(y[r].x), "+v"(y[r].y), "+v"(y[r].z), "+v"(y[r].w));
       const float yb = y_before(r);
       d[r][0].x = fmaf(Z.eps, yb, (y[r].x - yb) + mec);
       d[r][0].y = fmaf(Z.eps, y[r].x, (y[r].y - y[r].x) + mec);
