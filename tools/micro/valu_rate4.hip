@@ -43,6 +43,21 @@ __global__ void __launch_bounds__(256) k(const float* in, float* out, long long*
     else if constexpr (KIND == 7) asm volatile(R32(F3, 8) ::: CLOB_LO);
     else if constexpr (KIND == 8) asm volatile(R32(MV, 8) ::: CLOB_LO);
     else if constexpr (KIND == 9) asm volatile(R32(CN, 8) ::: CLOB_LO);
+    else if constexpr (KIND >= 10 && KIND <= 14) {
+      // one v_cmp -> vcc, K plain float instructions, one v_cndmask on that vcc (K = 0, 1, 3, 7), x8; KIND 14: vcc written by SALU first
+#define F1 "v_fmac_f32_e32 v20, v1, v2\n\t"
+#define GRP(FILL) "v_cmp_gt_f32_e32 vcc, v1, v2\n\t" FILL "v_cndmask_b32_e32 v8, v1, v2, vcc\n\t"
+#define GRS "s_mov_b64 vcc, s[20:21]\n\tv_cndmask_b32_e32 v8, v1, v2, vcc\n\t"
+      if constexpr (KIND == 10) asm volatile(GRP("") GRP("") GRP("") GRP("") GRP("") GRP("") GRP("") GRP("") ::: "v8", "v20", "vcc");
+      else if constexpr (KIND == 11) asm volatile(GRP(F1) GRP(F1) GRP(F1) GRP(F1) GRP(F1) GRP(F1) GRP(F1) GRP(F1) ::: "v8", "v20", "vcc");
+      else if constexpr (KIND == 12) asm volatile(GRP(F1 F1 F1) GRP(F1 F1 F1) GRP(F1 F1 F1) GRP(F1 F1 F1) GRP(F1 F1 F1) GRP(F1 F1 F1) GRP(F1 F1 F1) GRP(F1 F1 F1) ::: "v8", "v20", "vcc");
+      else if constexpr (KIND == 13) asm volatile(GRP(F1 F1 F1 F1 F1 F1 F1) GRP(F1 F1 F1 F1 F1 F1 F1) GRP(F1 F1 F1 F1 F1 F1 F1) GRP(F1 F1 F1 F1 F1 F1 F1) GRP(F1 F1 F1 F1 F1 F1 F1) GRP(F1 F1 F1 F1 F1 F1 F1) GRP(F1 F1 F1 F1 F1 F1 F1) GRP(F1 F1 F1 F1 F1 F1 F1) ::: "v8", "v20", "vcc");
+      else asm volatile(GRS GRS GRS GRS GRS GRS GRS GRS ::: "v8", "vcc", "s20", "s21");
+    }
+    else if constexpr (KIND == 15) {   // v_cmp into an SGPR pair, then v_cndmask_e64 on it directly
+#define GRE "v_cmp_gt_f32_e64 s[20:21], v1, v2\n\tv_cndmask_b32_e64 v8, v1, v2, s[20:21]\n\t"
+      asm volatile(GRE GRE GRE GRE GRE GRE GRE GRE ::: "v8", "s20", "s21");
+    }
     else if constexpr (KIND == 6) {
 #define PK(B, i) "v_pk_fma_f32 v[" STR(B) "+2*" STR(i) ":" STR(B) "+2*" STR(i) "+1], v[2:3], v[4:5], v[" STR(B) "+2*" STR(i) ":" STR(B) "+2*" STR(i) "+1]\n\t"
       asm volatile(PK(8, 0) PK(8, 1) PK(8, 2) PK(8, 3) PK(8, 4) PK(8, 5) PK(8, 6) PK(8, 7) PK(8, 8) PK(8, 9) PK(8, 10) PK(8, 11) PK(8, 12) PK(8, 13) PK(8, 14) PK(8, 15) ::: CLOB_LO);
@@ -89,5 +104,11 @@ int main() {
   run<7>("v_fma_f32 (VOP3) low", 32, in, out, cyc);
   run<8>("v_mov_b32 low", 32, in, out, cyc);
   run<9>("v_cndmask_b32_e32 vcc low", 32, in, out, cyc);
+  run<10>("[v_cmp vcc, v_cndmask vcc] x8 (16 instr)", 16, in, out, cyc);
+  run<11>("[v_cmp, 1 fmac, v_cndmask] x8 (24)", 24, in, out, cyc);
+  run<12>("[v_cmp, 3 fmac, v_cndmask] x8 (40)", 40, in, out, cyc);
+  run<13>("[v_cmp, 7 fmac, v_cndmask] x8 (72)", 72, in, out, cyc);
+  run<14>("[s_mov vcc, v_cndmask vcc] x8 (16)", 16, in, out, cyc);
+  run<15>("[v_cmp_e64 sgpr, v_cndmask_e64 sgpr] x8 (16)", 16, in, out, cyc);
   return 0;
 }
