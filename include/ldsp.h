@@ -81,7 +81,7 @@ int ldsp_ctx_last_kernel_ms(ldsp_ctx* ctx, float* ms);
  * one stage (asking for stage 1 is an LDSP_ERR_INVALID_ARG). */
 int ldsp_ctx_last_stage_ms(ldsp_ctx* ctx, int stage, float* ms);
 /* Name (inside namespace ldsp::, without template arguments) of the dominant kernel the last
- * ldsp_*_run call launched, e.g. "lean::icpc_lean_kernel" — the name rocprofv3 reports; a static
+ * ldsp_*_run call launched, e.g. "lean3::icpc_lean3_kernel" — the name rocprofv3 reports; a static
  * string, "" before the first launch. */
 const char* ldsp_ctx_last_kernel_name(ldsp_ctx* ctx);
 
