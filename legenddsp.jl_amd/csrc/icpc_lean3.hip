@@ -284,19 +284,37 @@ __device__ __forceinline__ f4 rdq(const float* X, int idx, int al) {
 // the lanes with (lane & 7) == 7 (row_shr inside a row of 16 lanes, zeros shifted in)
 __device__ __forceinline__ uint32_t s4_pack_word(uint32_t nib, int lane) {
   uint32_t v = nib << (4 * (lane & 7));
-  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+  // three fused OR steps in place (a lane whose source is out of the row ORs in zero: bound_ctrl), one asm statement
+  asm("s_nop 1\n\t"
+      "v_or_b32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+      "v_or_b32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+      "v_or_b32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+      : "+v"(v));
   return v;
 }
 // the thread index as a value hipcc cannot connect to its other copies: index arithmetic (4 (tid + NT r) + e, window-edge tests ..) is
 // recomputed in each phase — one VALU each — instead of living in a dozen registers from the first phase to the last
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// the four comparison bits of a quad as a nibble (bit e = sample e): compare into VCC, shift the bit in with an add-with-carry
+// (n = 2 n + bit), most significant sample first — eight instructions, each select-free and on a VCC the instruction before it wrote
+// (a NaN compares false, as in the C form)
 __device__ __forceinline__ uint32_t nib_ge(f4 v, float t) {
-  return (uint32_t)(v.x >= t) | ((uint32_t)(v.y >= t) << 1) | ((uint32_t)(v.z >= t) << 2) | ((uint32_t)(v.w >= t) << 3);
+  uint32_t n = 0;
+  asm("v_cmp_ge_f32_e32 vcc, %1, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_ge_f32_e32 vcc, %2, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_ge_f32_e32 vcc, %3, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_ge_f32_e32 vcc, %4, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+      : "+v"(n) : "v"(v.w), "v"(v.z), "v"(v.y), "v"(v.x), "v"(t) : "vcc");
+  return n;
 }
 __device__ __forceinline__ uint32_t nib_le(f4 v, float t) {
-  return (uint32_t)(v.x <= t) | ((uint32_t)(v.y <= t) << 1) | ((uint32_t)(v.z <= t) << 2) | ((uint32_t)(v.w <= t) << 3);
+  uint32_t n = 0;
+  asm("v_cmp_le_f32_e32 vcc, %1, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_le_f32_e32 vcc, %2, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_le_f32_e32 vcc, %3, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+      "v_cmp_le_f32_e32 vcc, %4, %5\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+      : "+v"(n) : "v"(v.w), "v"(v.z), "v"(v.y), "v"(v.x), "v"(t) : "vcc");
+  return n;
 }
 
 // LDSP_L3_WPS: minimum waves per SIMD the register allocation is bounded for (6: three 512-thread workgroups per CU, <= 80 VGPRs)
