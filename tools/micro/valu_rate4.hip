@@ -58,6 +58,16 @@ __global__ void __launch_bounds__(256) k(const float* in, float* out, long long*
 #define GRE "v_cmp_gt_f32_e64 s[20:21], v1, v2\n\tv_cndmask_b32_e64 v8, v1, v2, s[20:21]\n\t"
       asm volatile(GRE GRE GRE GRE GRE GRE GRE GRE ::: "v8", "s20", "s21");
     }
+    else if constexpr (KIND == 16 || KIND == 17) {   // cross-lane swaps of gfx950 (the halving steps of a multi-value reduction)
+#define SW32(B, i) "v_permlane32_swap_b32_e32 v[" STR(B) "+" STR(i) "], v1\n\t"
+#define SW16(B, i) "v_permlane16_swap_b32_e32 v[" STR(B) "+" STR(i) "], v1\n\t"
+      if constexpr (KIND == 16) asm volatile(R32(SW32, 8) ::: CLOB_LO, "v1");
+      else asm volatile(R32(SW16, 8) ::: CLOB_LO, "v1");
+    }
+    else if constexpr (KIND == 18) {   // v_add_f32_dpp row_shr (in place, independent registers)
+#define DP(B, i) "v_add_f32_dpp v[" STR(B) "+" STR(i) "], v[" STR(B) "+" STR(i) "], v[" STR(B) "+" STR(i) "] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      asm volatile(R32(DP, 8) ::: CLOB_LO);
+    }
     else if constexpr (KIND == 6) {
 #define PK(B, i) "v_pk_fma_f32 v[" STR(B) "+2*" STR(i) ":" STR(B) "+2*" STR(i) "+1], v[2:3], v[4:5], v[" STR(B) "+2*" STR(i) ":" STR(B) "+2*" STR(i) "+1]\n\t"
       asm volatile(PK(8, 0) PK(8, 1) PK(8, 2) PK(8, 3) PK(8, 4) PK(8, 5) PK(8, 6) PK(8, 7) PK(8, 8) PK(8, 9) PK(8, 10) PK(8, 11) PK(8, 12) PK(8, 13) PK(8, 14) PK(8, 15) ::: CLOB_LO);
@@ -104,6 +114,9 @@ int main() {
   run<7>("v_fma_f32 (VOP3) low", 32, in, out, cyc);
   run<8>("v_mov_b32 low", 32, in, out, cyc);
   run<9>("v_cndmask_b32_e32 vcc low", 32, in, out, cyc);
+  run<16>("v_permlane32_swap_b32", 32, in, out, cyc);
+  run<17>("v_permlane16_swap_b32", 32, in, out, cyc);
+  run<18>("v_add_f32_dpp row_shr:1 (independent)", 32, in, out, cyc);
   run<10>("[v_cmp vcc, v_cndmask vcc] x8 (16 instr)", 16, in, out, cyc);
   run<11>("[v_cmp, 1 fmac, v_cndmask] x8 (24)", 24, in, out, cyc);
   run<12>("[v_cmp, 3 fmac, v_cndmask] x8 (40)", 40, in, out, cyc);
