@@ -292,6 +292,9 @@ __device__ __forceinline__ uint32_t s4_pack_word(uint32_t nib, int lane) {
       : "+v"(v));
   return v;
 }
+// sample e of a quad inside the window [lo, hi] (both relative to the quad's first sample): ONE unsigned comparison, e - lo <= hi - lo —
+// the two-sided form compiles to two compares joined by s_and_b64, and a select on a mask that SALU wrote stalls (tools/micro/valu_rate4.hip)
+__device__ __forceinline__ bool in_win(int e, int lo, uint32_t span) { return (uint32_t)(e - lo) <= span; }
 // the thread index as a value hipcc cannot connect to its other copies: index arithmetic (4 (tid + NT r) + e, window-edge tests ..) is
 // recomputed in each phase — one VALU each — instead of living in a dozen registers from the first phase to the last
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -420,8 +423,8 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       f2 d0 = x[r].xy, d1 = x[r].zw;
       if (!row_in(cls_bl, r)) {
         const int i0 = 4 * (opaque(tid) + NT * r), lo = P.bl.from - i0, hi = P.bl.until - i0;   // in-window e in [lo, hi]
-        d0.x = (lo <= 0 && hi >= 0) ? d0.x : 0.f; d0.y = (lo <= 1 && hi >= 1) ? d0.y : 0.f;
-        d1.x = (lo <= 2 && hi >= 2) ? d1.x : 0.f; d1.y = (lo <= 3 && hi >= 3) ? d1.y : 0.f;
+        d0.x = in_win(0, lo, (uint32_t)(hi - lo)) ? d0.x : 0.f; d0.y = in_win(1, lo, (uint32_t)(hi - lo)) ? d0.y : 0.f;
+        d1.x = in_win(2, lo, (uint32_t)(hi - lo)) ? d1.x : 0.f; d1.y = in_win(3, lo, (uint32_t)(hi - lo)) ? d1.y : 0.f;
       }
       wacc_quad(a, d0, d1, r);
     }
@@ -553,15 +556,15 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         const bool edge = !row_in(cls_tail, r);
         const int lo = P.tail.from - i0, hi = P.tail.until - i0;
         if (edge) {   // samples outside the window must not trip the sign test
-          v0.x = (lo <= 0 && hi >= 0) ? v0.x : 1.f; v0.y = (lo <= 1 && hi >= 1) ? v0.y : 1.f;
-          v1.x = (lo <= 2 && hi >= 2) ? v1.x : 1.f; v1.y = (lo <= 3 && hi >= 3) ? v1.y : 1.f;
+          v0.x = in_win(0, lo, (uint32_t)(hi - lo)) ? v0.x : 1.f; v0.y = in_win(1, lo, (uint32_t)(hi - lo)) ? v0.y : 1.f;
+          v1.x = in_win(2, lo, (uint32_t)(hi - lo)) ? v1.x : 1.f; v1.y = in_win(3, lo, (uint32_t)(hi - lo)) ? v1.y : 1.f;
         }
         tmin = vmin3(tmin, v0.x, v0.y); tmin = vmin3(tmin, v1.x, v1.y);
         f2 d0 = mk2(__logf(fmaxf(v0.x, 1e-30f)), __logf(fmaxf(v0.y, 1e-30f))) - pvl;
         f2 d1 = mk2(__logf(fmaxf(v1.x, 1e-30f)), __logf(fmaxf(v1.y, 1e-30f))) - pvl;
         if (edge) {
-          d0.x = (lo <= 0 && hi >= 0) ? d0.x : 0.f; d0.y = (lo <= 1 && hi >= 1) ? d0.y : 0.f;
-          d1.x = (lo <= 2 && hi >= 2) ? d1.x : 0.f; d1.y = (lo <= 3 && hi >= 3) ? d1.y : 0.f;
+          d0.x = in_win(0, lo, (uint32_t)(hi - lo)) ? d0.x : 0.f; d0.y = in_win(1, lo, (uint32_t)(hi - lo)) ? d0.y : 0.f;
+          d1.x = in_win(2, lo, (uint32_t)(hi - lo)) ? d1.x : 0.f; d1.y = in_win(3, lo, (uint32_t)(hi - lo)) ? d1.y : 0.f;
         }
         wacc_quad(a, d0, d1, r);
       }
@@ -789,8 +792,8 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       f2 d0 = y[r].xy - pvz, d1 = y[r].zw - pvz;
       if (!row_in(cls_tail, r)) {
         const int lo = P.tail.from - i0, hi = P.tail.until - i0;
-        d0.x = (lo <= 0 && hi >= 0) ? d0.x : 0.f; d0.y = (lo <= 1 && hi >= 1) ? d0.y : 0.f;
-        d1.x = (lo <= 2 && hi >= 2) ? d1.x : 0.f; d1.y = (lo <= 3 && hi >= 3) ? d1.y : 0.f;
+        d0.x = in_win(0, lo, (uint32_t)(hi - lo)) ? d0.x : 0.f; d0.y = in_win(1, lo, (uint32_t)(hi - lo)) ? d0.y : 0.f;
+        d1.x = in_win(2, lo, (uint32_t)(hi - lo)) ? d1.x : 0.f; d1.y = in_win(3, lo, (uint32_t)(hi - lo)) ? d1.y : 0.f;
       }
       wacc_quad(a, d0, d1, r);
     }
@@ -868,7 +871,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         if (!row_in(cls_sgbl, r)) {
           const int lo = P.sgbl.from - i0, hi = P.sgbl.until - i0;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dd[e] = (lo <= e && hi >= e) ? dd[e] : 0.f;
+          for (int e = 0; e < 4; ++e) dd[e] = in_win(e, lo, (uint32_t)(hi - lo)) ? dd[e] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { g_s1 += dd[e]; g_s2 = fmaf(dd[e], dd[e], g_s2); }
