@@ -324,6 +324,9 @@ __device__ __forceinline__ uint32_t nib_le(f4 v, float t) {
 #ifndef LDSP_L3_WPS
 #define LDSP_L3_WPS 6
 #endif
+#ifndef LDSP_L3_TAB0   // 1: the cross-wave tables of the first exchange are computed by wave 0 only (see there)
+#define LDSP_L3_TAB0 1
+#endif
 #ifndef LDSP_L3_RWPS   // the same for traces shorter than the tile (their bounds cost registers)
 #define LDSP_L3_RWPS 6
 #endif
@@ -446,11 +449,13 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   }
   STAMP(1); DSTOP(1);
   __syncthreads();
-  // State entering each wave-row, lane j <-> wave-row j in time order (r = j / NW, w = j % NW).  EVERY wave scans the R*NW totals
-  // for itself (~70 instructions) and takes its own rows' entries by v_readlane: no serial section of one wave with everybody
-  // waiting at a second barrier.  Wave 0 also leaves the tables in LDS for the CUSP / ZAC stage.
-  float tab_hi, tab_lo, tab_b;   // lane j: T at wave-row j's first sample (without the delta terms) as hi + lo; c * (sum of x' before it)
-  {
+  // State entering each wave-row, lane j <-> wave-row j in time order (r = j / NW, w = j % NW).  LDSP_L3_TAB0 = 0: EVERY wave scans
+  // the R*NW totals for itself (~120 instructions) and takes its own rows' entries by v_readlane — no wave waits for another (right
+  // while the kernel waited on latency).  LDSP_L3_TAB0 = 1 (default since the VALU became the busy unit): wave 0
+  // scans them for everybody while the other waves go on with the tail logarithms, which need the baseline mean only; one more barrier
+  // in front of the y / T loop, whose rows then come from the table in LDS (which the CUSP / ZAC stage wants there anyway).
+  float tab_hi = 0.f, tab_lo = 0.f, tab_b = 0.f;   // lane j: T at wave-row j's first sample (without the delta terms) as hi + lo; c * (sum of x' before it)
+  if (!LDSP_L3_TAB0 || wave == 0) {
     const int jr = lane / NW, jw = lane - jr * NW;
     const bool in = lane < R * NW;
     // C1_j = sum_{j'<j} S_j',  C2_j = sum_{j'<j} (Q_j' + 256 C1_j') = sum_{j'<j} Q_j' + 256 ((j-1) sum_{j'<j} S_j' - sum_{j'<j} j' S_j'):
@@ -576,6 +581,9 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+#if LDSP_L3_TAB0
+    __syncthreads();   // wave 0's tables are in LDS
+#endif
     // ---- y (registers) and T (-> X) of every quad
     const float c = P.pz_c, cd = c * delta, hc = 0.5f * c;
     const float n0 = (float)(4 * lane);
@@ -583,7 +591,11 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     for (int r = 0; r < R; ++r) {
       const int i0 = 4 * (opaque(tid) + NT * r);
       const float fi = (float)i0;
+#if LDSP_L3_TAB0
+      const float Hr = readlane_f(S.scn[4 * wave + r], 0), Lr = readlane_f(S.scn[R * NW + 4 * wave + r], 0), Br = readlane_f(S.scn[2 * R * NW + 4 * wave + r], 0);   // the row's entries (wave-uniform addresses)
+#else
       const float Hr = readlane_f(tab_hi, r * NW + wave), Lr = readlane_f(tab_lo, r * NW + wave), Br = readlane_f(tab_b, r * NW + wave);   // the row's entries
+#endif
       const float c0 = x[r].x, c1 = c0 + x[r].y, c2 = c1 + x[r].z, c3 = c2 + x[r].w;   // running sums of x' inside the quad
       const f4 xs = (f4){x[r].x - delta, x[r].y - delta, x[r].z - delta, x[r].w - delta};   // shift_waveform
       // y[i] = x[i] + c (C1 + cs_l) - c delta (i+1),  c C1 = B,  cs_l(e) = ex1 + c_e
