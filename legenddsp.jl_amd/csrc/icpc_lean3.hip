@@ -1681,10 +1681,9 @@ size_t icpc_lean3_smem_bytes(int NT, int Lf) {
 }
 
 // sg_slots: 7 or 13 (the smallest that holds the three Savitzky-Golay windows)
-// full: the traces fill the tile (L = 16 NT); shorter traces (L % 4 == 0) only with shared CUSP / ZAC geometry
+// full: the traces fill the tile (L = 16 NT); otherwise shorter traces (L % 4 == 0, more than half the tile)
 hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, bool full, const IcpcDev* dP, const IcpcOutDev& out,
                              const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st) {
-  if (!full && !cz_shared) return hipErrorInvalidValue;
 #ifdef LDSP_DEV_512
 #define LDSP_LEAN_CASES LDSP_CASE(512)
 #else
@@ -1693,7 +1692,8 @@ hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, b
 #define LDSP_ARGS wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st
 #define LDSP_CASE(N) \
   case N: \
-    if (!full) return sg_slots <= 7 ? lean3::launch_t<N, 7, false, false>(LDSP_ARGS) : lean3::launch_t<N, 13, false, false>(LDSP_ARGS); \
+    if (!full) return cz_shared ? (sg_slots <= 7 ? lean3::launch_t<N, 7, false, false>(LDSP_ARGS) : lean3::launch_t<N, 13, false, false>(LDSP_ARGS)) \
+                                : (sg_slots <= 7 ? lean3::launch_t<N, 7, true, false>(LDSP_ARGS) : lean3::launch_t<N, 13, true, false>(LDSP_ARGS)); \
     return cz_shared ? (sg_slots <= 7 ? lean3::launch_t<N, 7, false, true>(LDSP_ARGS) : lean3::launch_t<N, 13, false, true>(LDSP_ARGS)) \
                      : (sg_slots <= 7 ? lean3::launch_t<N, 7, true, true>(LDSP_ARGS) : lean3::launch_t<N, 13, true, true>(LDSP_ARGS));
   switch (NT) {

@@ -453,7 +453,7 @@ static bool icpc_lean_applies(const ldsp_ctx* c, bool full_tile = false) {
   const IcpcDev& H = c->icpc_host;
   const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
   if (c->icpc_generic || c->two_kernel || !(c->dbg_stop == 0 || c->dbg_stop >= 100) || H.R != 4 || H.L > 16 * H.NT || H.NT > 512 ||
-      (H.L & 3) != 0 || H.L <= 8 * H.NT || ((full_tile || !H.cz_shared) && H.L != 16 * H.NT) ||   // (more than half the tile: its first two rows are in the trace)
+      (H.L & 3) != 0 || H.L <= 8 * H.NT || (full_tile && H.L != 16 * H.NT) ||   // (more than half the tile: its first two rows are in the trace)
       H.cusp_mode != 1 || !H.t0inv_same || H.tx_mintot > 2 || sg_max > 13)
     return false;
   const double rail = std::max(std::fabs((double)H.sat_high), std::fabs((double)H.sat_low)) * (double)H.L;

@@ -257,9 +257,10 @@ def test_threshold_crossings_with_spikes_before_the_pulse(orc, params):
         # the spikes did what they were meant to: traces 0..15 keep their crossing at the pulse, 16..23 moved to the spike pair
         assert np.all(gpu["t10"][:16] > 40.0) and np.all(gpu["t10"][16:24] < 20.0)
 
-@pytest.mark.parametrize("length,kernel", [(8000, "lean3::icpc_lean3_kernel"), (7300, "lean3::icpc_lean3_kernel"), (4400, "lean3::icpc_lean3_kernel"),
-                                            (8190, "icpc_kernel"), (7301, "icpc_kernel")])
-def test_traces_shorter_than_the_tile(orc, length, kernel):
+@pytest.mark.parametrize("length,kernel,sep", [(8000, "lean3::icpc_lean3_kernel", False), (7300, "lean3::icpc_lean3_kernel", False),
+                                                (4400, "lean3::icpc_lean3_kernel", False), (7600, "lean3::icpc_lean3_kernel", True),
+                                                (8190, "icpc_kernel", False), (7301, "icpc_kernel", False)])
+def test_traces_shorter_than_the_tile(orc, length, kernel, sep):
     """A trace that does not fill the tile (16 x threads samples) still runs the fused lean kernel when its rows are 16-byte
     aligned (length % 4 == 0: quads are loaded whole; the lanes beyond the trace load its last quad again and every output range
     is bounded by the length) — 8000-, 7300-, 4400-sample traces; other lengths run icpc_kernel.  Both against the oracle on
@@ -272,7 +273,8 @@ def test_traces_shorter_than_the_tile(orc, length, kernel):
                               bl_window=ldsp.ClosedInterval(0.0, 39.0 * us * sc), tail_window=ldsp.ClosedInterval(70.0 * us * sc, (length - 1) * dt),
                               current_window=ldsp.ClosedInterval(43.0 * us * sc, 62.0 * us * sc),
                               flt_length_cusp=38.0 * us * sc, flt_length_zac=38.0 * us * sc)
-    p = ldsp.lower_icpc(cfg, 500 * us, {}, length, 0.0, dt)
+    pf = {"cusp": {"rt": 4.0 * us * sc, "ft": 1.5 * us * sc}, "zac": {"rt": 5.5 * us * sc, "ft": 2.0 * us * sc}} if sep else {}   # sep: two passes of the closed-form stage
+    p = ldsp.lower_icpc(cfg, 500 * us, pf, length, 0.0, dt)
     n = 128
     wf = ldsp.synth.hpge_batch(n, 8192, device="cuda", seed=61)
     idx = (torch.arange(length, device="cuda", dtype=torch.float32) / sc).long().clamp(max=8191)
