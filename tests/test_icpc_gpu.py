@@ -51,6 +51,21 @@ def test_icpc_matches_oracle_seeded_batch(orc, params, direct, generic):
     assert worst <= parity.FLIP_FRAC, "\n".join(lines)
 
 
+def test_synthetic_batch_is_the_same_on_host_and_device():
+    """the synthetic input is counter-based so that the bench batch can be regenerated anywhere — any rows of it, on the
+    host: 64 traces from the middle of the 1 M-trace batch, generated on the GPU and on the CPU, are the same numbers (the integer
+    hash is exact on both; the Gaussian transform is rounded to float32 from double, so at most a last-place difference in isolated
+    samples)."""
+    a = ldsp.synth.hpge_batch(64, L, device="cuda", first_trace=500_000).cpu()
+    b = ldsp.synth.hpge_batch(64, L, device="cpu", first_trace=500_000)
+    diff = a != b
+    assert int(diff.sum()) <= 8, int(diff.sum())                      # of 524 288 samples
+    assert float((a - b).abs().max()) <= 2.5e-4                        # one ulp at 1e3 .. 2e4 ADC counts
+    s1 = ldsp.synth.sipm_batch(16, 16384, device="cuda", first_trace=300_000).cpu()
+    s2 = ldsp.synth.sipm_batch(16, 16384, device="cpu", first_trace=300_000)
+    assert float((s1 - s2).abs().max()) <= 2e-6 and int((s1 != s2).sum()) <= 64
+
+
 def test_lean_and_generic_kernels_agree(params):
     """The two implementations of the chain (icpc_lean3_kernel: pivoted sums, one exchange; icpc_kernel: the round-1 form) against
     EACH OTHER on the seeded batch, tighter than either is held to the oracle: a regression in the run-count or mask logic of one
