@@ -54,7 +54,14 @@ int ldsp_abi_version(void);
 int ldsp_ctx_create(int device, ldsp_ctx** out);
 int ldsp_ctx_destroy(ldsp_ctx* ctx);
 /* Launch on an existing hipStream_t (e.g. torch's current stream).  NULL is the
- * device's default (null) stream, exactly as in the HIP API. */
+ * device's default (null) stream, exactly as in the HIP API.
+ * Lifetime: the stream belongs to the caller and must stay valid while the
+ * context launches on it.  A change of stream orders the new stream behind the
+ * work queued on the previous one (the context's workspaces are shared by all
+ * launches): by an event when the previous stream can still record one, else
+ * — the previous stream was destroyed, or is being captured — by a device
+ * synchronisation; the new stream is adopted either way, so a context can
+ * always leave a stream its owner has already released. */
 int ldsp_ctx_set_stream(ldsp_ctx* ctx, void* hip_stream);
 /* Back to the context's own non-blocking stream (the initial state). */
 int ldsp_ctx_use_own_stream(ldsp_ctx* ctx);
@@ -63,8 +70,10 @@ const char* ldsp_last_error_string(void);
 /* Options: "cusp_direct" = 1 evaluates CUSP/ZAC as direct-form FIR (slow
  * comparator for the closed-form recursions), 0 (default) = recursions.
  * "two_kernel" = 1 runs the CUSP/ZAC stage as a second launch (icpc_cz_kernel)
- * instead of fused into icpc_kernel (the default whenever CUSP and ZAC share
- * their geometry and the LDS budget allows two traces per CU).
+ * instead of fused into the dsp_icpc launch (the default: icpc_lean3_kernel,
+ * three traces per CU, for the standard geometry; the generic icpc_kernel, two
+ * traces per CU, whenever CUSP and ZAC share their geometry and its LDS budget
+ * allows).
  * "dbg_stop" = k stops the kernels after phase k (profiling aid; outputs are
  * then incomplete). */
 int ldsp_ctx_set_option(ldsp_ctx* ctx, const char* key, int64_t value);

@@ -163,6 +163,14 @@ class Context:
             s = torch.cuda.current_stream(self.device).cuda_stream
             check(lib().ldsp_ctx_set_stream(self._h, _VOIDP(s)))
 
+    def set_stream(self, hip_stream):
+        """Launch on the given hipStream_t (an integer handle, e.g. torch.cuda.Stream().cuda_stream; 0 / None = the null stream).  The
+        stream stays the caller's: see the lifetime rule in include/ldsp.h.  Use with use_torch_stream=False."""
+        check(lib().ldsp_ctx_set_stream(self._h, _VOIDP(hip_stream or None)))
+
+    def use_own_stream(self):
+        check(lib().ldsp_ctx_use_own_stream(self._h))
+
     @property
     def handle(self):
         return self._h

@@ -141,9 +141,9 @@ struct IcpcDev {
   const float* h_cusp; // device, true-convolution taps (mode 0)
   const float* h_zac;
   // lean kernel: how window w (0 bl, 1 tail, 2 SG baseline, 3 current window of SG filter 0, 4 union of the other current
-  // windows) meets the four 256-sample rows of wave v in the S4 view: bit r = row r lies outside the window, bit 4+r = wholly
-  // inside (else it holds an edge)
-  uint32_t rowcls[5][16];
+  // windows, 5 their intersection) meets the four 256-sample rows of wave v in the S4 view: bit r = row r lies outside the window,
+  // bit 4+r = wholly inside (else it holds an edge)
+  uint32_t rowcls[6][16];
   long long* dbg_stamps;   // diagnostic builds (LDSP_STAMPS) only: [LDSP_STAMP_BLOCKS][16 waves][LDSP_STAMP_SLOTS] s_memtime stamps
 };
 #define LDSP_STAMP_BLOCKS 2048

@@ -35,6 +35,37 @@
 #define DSTOP(id) do { } while (0)
 #endif
 
+// what-if builds (timing experiments with wrong results, never shipped): -DLDSP_WHATIF_NOBAR_CZ / -DLDSP_WHATIF_NOBAR_MAIN drop the barriers
+#ifdef LDSP_WHATIF_NOBAR_CZ
+#define LDSP_BAR_CZ() ((void)0)
+#else
+#define LDSP_BAR_CZ() __syncthreads()
+#endif
+#ifdef LDSP_WHATIF_NOBAR_MAIN
+#define LDSP_BAR_MAIN() ((void)0)
+#else
+#define LDSP_BAR_MAIN() __syncthreads()
+#endif
+
+// sensitivity probes (timing experiments: -DLDSP_PROBE_VALU=n / _LDS=n / _SALU=n adds n instructions of that kind at each of eight places)
+#ifndef LDSP_PROBE_VALU
+#define LDSP_PROBE_VALU 0
+#endif
+#ifndef LDSP_PROBE_LDS
+#define LDSP_PROBE_LDS 0
+#endif
+#ifndef LDSP_PROBE_SALU
+#define LDSP_PROBE_SALU 0
+#endif
+#define LDSP_PROBE() do { \
+    if (LDSP_PROBE_VALU) { float pa_ = 1.f, pb_ = 2.f; _Pragma("unroll") for (int pi_ = 0; pi_ < LDSP_PROBE_VALU; pi_ += 4) \
+        asm volatile("v_fmac_f32_e32 %0, %1, %1\n\tv_fmac_f32_e32 %1, %0, %0\n\tv_fmac_f32_e32 %0, %1, %1\n\tv_fmac_f32_e32 %1, %0, %0" : "+v"(pa_), "+v"(pb_)); } \
+    if (LDSP_PROBE_LDS) { float pl_[4]; _Pragma("unroll") for (int pi_ = 0; pi_ < LDSP_PROBE_LDS; pi_ += 4) { \
+        _Pragma("unroll") for (int pj_ = 0; pj_ < 4; ++pj_) pl_[pj_] = S.X[threadIdx.x + NT * (pi_ + pj_)]; \
+        asm volatile("" :: "v"(pl_[0]), "v"(pl_[1]), "v"(pl_[2]), "v"(pl_[3])); } } \
+    if (LDSP_PROBE_SALU) { int ps_ = 1; _Pragma("unroll") for (int pi_ = 0; pi_ < LDSP_PROBE_SALU; pi_ += 4) \
+        asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1" : "+s"(ps_)); } \
+  } while (0)
 namespace ldsp {
 extern int g_dbg_lds_pad;   // option "dbg_lds_pad" (defined in icpc_lean.hip)
 namespace lean3 {
@@ -292,6 +323,20 @@ __device__ __forceinline__ uint32_t s4_pack_word(uint32_t nib, int lane) {
       : "+v"(v));
   return v;
 }
+// four words at once: the steps of the four chains interleave, so the two wait states between a step's write and the next step's DPP
+// read of the same register are filled by the other chains (s4_pack_word alone: an s_nop in front of every step)
+__device__ __forceinline__ void s4_pack4(uint32_t (&w)[4], int lane) {
+  const int sh = 4 * (lane & 7);
+  w[0] <<= sh; w[1] <<= sh; w[2] <<= sh; w[3] <<= sh;
+#define LDSP_OR4(CTL) "v_or_b32_dpp %0, %0, %0 " CTL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" "v_or_b32_dpp %1, %1, %1 " CTL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+                     "v_or_b32_dpp %2, %2, %2 " CTL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" "v_or_b32_dpp %3, %3, %3 " CTL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#ifdef LDSP_WHATIF_S16
+  asm("s_nop 1\n\tv_or_b32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(w[0]));
+#else
+  asm("s_nop 1\n\t" LDSP_OR4("row_shr:1") LDSP_OR4("row_shr:2") LDSP_OR4("row_shr:4") : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+#endif
+#undef LDSP_OR4
+}
 // sample e of a quad inside the window [lo, hi] (both relative to the quad's first sample): ONE unsigned comparison, e - lo <= hi - lo —
 // the two-sided form compiles to two compares joined by s_and_b64, and a select on a mask that SALU wrote stalls (tools/micro/valu_rate4.hip)
 __device__ __forceinline__ bool in_win(int e, int lo, uint32_t span) { return (uint32_t)(e - lo) <= span; }
@@ -320,6 +365,9 @@ __device__ __forceinline__ uint32_t nib_le(f4 v, float t) {
   return n;
 }
 
+#ifndef LDSP_L3_SGC_VGPR
+#define LDSP_L3_SGC_VGPR 0   // (1, measured: taps of the SG pass alone +-0, all loop constants -0.9 %: the copies and three spilled registers cost more) loop constants (filter taps, decay factors) live in vector registers: an instruction with a scalar source issues at 1.5x the cost of one without (tools/micro/valu_cost.hip)
+#endif
 // LDSP_L3_WPS: minimum waves per SIMD the register allocation is bounded for (6: three 512-thread workgroups per CU, <= 80 VGPRs)
 #ifndef LDSP_L3_WPS
 #define LDSP_L3_WPS 6
@@ -341,6 +389,11 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   static_assert(R * NW <= 64, "wave-row partials must fit one wave");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const IcpcDev& P = *Pp;
+#ifdef LDSP_ISA_STUDY   // static ISA of the bench configuration's path only (tools/l3_asm.sh -DLDSP_ISA_STUDY): never a product build
+  constexpr bool STUDY = true;
+#else
+  constexpr bool STUDY = false;
+#endif
   // Trace length: the tile (Lp = 16 NT samples) or less (L % 4 == 0, the host admits nothing else).  Lanes whose quad lies beyond
   // L load the trace's last quad once more: real sample values, so the raw extremes are unchanged; every filter of the chain is
   // causal up to its own output range, every output range is bounded by L below (nout, ng, the crossing tests), and the one
@@ -353,9 +406,9 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   SM S(smem_raw, cz_pad_floats(Lf_max));
   const float* w = wf + (size_t)blockIdx.x * (size_t)L;
   auto wrow = [&](int r) { return 4 * (64 * wave + NT * r); };
-  enum { WN_BL, WN_TAIL, WN_SGBL, WN_CUR0, WN_CURX };
+  enum { WN_BL, WN_TAIL, WN_SGBL, WN_CUR0, WN_CURX, WN_CURI };
   const uint32_t cls_bl = P.rowcls[WN_BL][wave], cls_tail = P.rowcls[WN_TAIL][wave], cls_sgbl = P.rowcls[WN_SGBL][wave],
-                 cls_cur0 = P.rowcls[WN_CUR0][wave], cls_curx = P.rowcls[WN_CURX][wave];
+                 cls_cur0 = P.rowcls[WN_CUR0][wave], cls_curx = P.rowcls[WN_CURX][wave], cls_curi = P.rowcls[WN_CURI][wave];
   auto row_out = [&](uint32_t cls, int r) { return ((cls >> r) & 1u) != 0u; };
   auto row_in = [&](uint32_t cls, int r) { return ((cls >> (4 + r)) & 1u) != 0u; };
 
@@ -363,10 +416,10 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   STAMP(0); DSTOP(0);
   f4 x[R];
   const uint16_t* w16 = reinterpret_cast<const uint16_t*>(wf) + (size_t)blockIdx.x * (size_t)L;
-  auto wv = [&](int i) { return P.in_u16 ? (float)w16[i] : w[i]; };
+  auto wv = [&](int i) { return (!STUDY && P.in_u16) ? (float)w16[i] : w[i]; };
   // (!FULL: the tile is the smallest that holds the trace, so rows 0 and 1 lie inside it; a lane whose quad of row 2 or 3 lies beyond
   // the trace keeps a copy of its own row-0 quad there — real sample values: the raw extremes do not change)
-  if (P.in_u16) {   // (block-uniform)
+  if ((!STUDY && P.in_u16)) {   // (block-uniform)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (!FULL && r >= 2) { x[r] = x[0]; if (4 * (tid + NT * r) >= L) continue; }
@@ -381,8 +434,12 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     }
   }
   const float pv_bl = wv(P.bl.from);      // pivot of the baseline sums: the window's first sample
-  for (int i = tid; i < 2 * EST_TBL; i += NT)   // LSQ basis tables of the two estimators -> LDS
-    S.estB[i] = (i < EST_TBL) ? P.sig_est.B[i] : P.int_est.B[i - EST_TBL];
+  // LSQ basis tables of the two estimators -> LDS: both loads of a thread in flight together, and no loop where the tile has a thread per entry
+  if constexpr (NT >= EST_TBL) {
+    if (tid < EST_TBL) { const float a = P.sig_est.B[tid], b = P.int_est.B[tid]; S.estB[tid] = a; S.estB[EST_TBL + tid] = b; }
+  } else {
+    for (int i = tid; i < EST_TBL; i += NT) { const float a = P.sig_est.B[i], b = P.int_est.B[i]; S.estB[i] = a; S.estB[EST_TBL + i] = b; }
+  }
   if (tid < (int)(sizeof(Slots) / 4)) {
     const int o = tid * 4;
     uint32_t init = 0;
@@ -434,10 +491,18 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     float s1, s2, sx;
     wacc_lane<NT>(a, tid, (float)P.bl.ic, &s1, &s2, &sx);
     LDSP_DPP_GROUP5("v_add_f32_dpp", s1, "v_add_f32_dpp", s2, "v_add_f32_dpp", sx, "v_max_f32_dpp", rmax, "v_min_f32_dpp", rmin);
+#ifdef LDSP_WHATIF_S16
+    LDSP_DPP_GROUP1("v_add_f32_dpp", i1[0]);
+#else
     LDSP_DPP_GROUP4("v_add_f32_dpp", i1[0], "v_add_f32_dpp", i1[1], "v_add_f32_dpp", i1[2], "v_add_f32_dpp", i1[3]);
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) { ex1[r] = i1[r] - t[r]; i2[r] = fmaf(4.f, ex1[r], q2[r]); ex2[r] = i2[r]; }
+#ifdef LDSP_WHATIF_S16
+    LDSP_DPP_GROUP1("v_add_f32_dpp", i2[0]);
+#else
     LDSP_DPP_GROUP4("v_add_f32_dpp", i2[0], "v_add_f32_dpp", i2[1], "v_add_f32_dpp", i2[2], "v_add_f32_dpp", i2[3]);
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) ex2[r] = i2[r] - ex2[r];
     if (lane == 63) {
@@ -448,14 +513,18 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     }
   }
   STAMP(1); DSTOP(1);
-  __syncthreads();
+  LDSP_BAR_MAIN();
   // State entering each wave-row, lane j <-> wave-row j in time order (r = j / NW, w = j % NW).  LDSP_L3_TAB0 = 0: EVERY wave scans
   // the R*NW totals for itself (~120 instructions) and takes its own rows' entries by v_readlane — no wave waits for another (right
   // while the kernel waited on latency).  LDSP_L3_TAB0 = 1 (default since the VALU became the busy unit): wave 0
   // scans them for everybody while the other waves go on with the tail logarithms, which need the baseline mean only; one more barrier
   // in front of the y / T loop, whose rows then come from the table in LDS (which the CUSP / ZAC stage wants there anyway).
   float tab_hi = 0.f, tab_lo = 0.f, tab_b = 0.f;   // lane j: T at wave-row j's first sample (without the delta terms) as hi + lo; c * (sum of x' before it)
+#ifdef LDSP_WHATIF_S16
+  if (false) {
+#else
   if (!LDSP_L3_TAB0 || wave == 0) {
+#endif
     const int jr = lane / NW, jw = lane - jr * NW;
     const bool in = lane < R * NW;
     // C1_j = sum_{j'<j} S_j',  C2_j = sum_{j'<j} (Q_j' + 256 C1_j') = sum_{j'<j} Q_j' + 256 ((j-1) sum_{j'<j} S_j' - sum_{j'<j} j' S_j'):
@@ -480,7 +549,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     const float mn = fold_partials<NW>(S.wred + 4 * NW, INFINITY, [](float a, float b) { return vmin(a, b); });
     delta = s * (float)P.bl.inv_n;
     blmean = fmaf(s, (float)P.bl.inv_n, pv_bl);   // (the statement of pz_trap_lean_kernel, icpc_lean.hip: config 2 reports the same bits)
-    if (ext_bl) { blmean = ext_bl[blockIdx.x] * ext_bl_scale; delta = blmean - pv_bl; }   // windowed traces of dsp_icpc_compressed (dsp_icpc.jl:353)
+    if (!STUDY && ext_bl) { blmean = ext_bl[blockIdx.x] * ext_bl_scale; delta = blmean - pv_bl; }   // windowed traces of dsp_icpc_compressed (dsp_icpc.jl:353)
     raw_max = mx; raw_min = mn;
   }
   const float e_max = raw_max - blmean;
@@ -492,13 +561,13 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   // saturation (src/saturation.jl:28-65): only a trace whose extremes reach a rail can have saturated samples
   {
     int n_low = 0, n_high = 0, cons_low = 0, cons_high = 0;
-    if (raw_min <= P.sat_low || raw_max >= P.sat_high) {   // block-uniform, rare
+    if (!STUDY && (raw_min <= P.sat_low || raw_max >= P.sat_high)) {   // block-uniform, rare
       const float lo_ = P.sat_low, hi_ = P.sat_high;   // exact equality on the RAW samples: read again (the registers hold x')
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         f4 v;
         const int i0 = 4 * (tid + NT * r);
-        if (P.in_u16) {
+        if ((!STUDY && P.in_u16)) {
           const uint2 q = *reinterpret_cast<const uint2*>(w16 + in_trace(i0));
           v = (f4){(float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16)};
         } else {
@@ -545,7 +614,13 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   }
   // ---- y (registers) and T (-> X) of every quad; tailstats sums of log(x) on the way (src/tailstats.jl:22-72)
   {
-    const float pv_tl = __logf(fmaxf(wv(P.tail.from) - blmean, 1e-30f));   // pivot of the log sums
+    // The sums run in log2 units (v_log_f32 alone: `__logf` expands to a dozen instructions of denormal scaling and an extended-precision
+    // product with ln 2 that a float sum about a pivot cannot use) and are converted once, by the finishing lane.  Pivot: log2 of the
+    // window's first sample x_p; a sample of an edge row that lies outside the window is replaced by x_p itself, whose term
+    // log2(x_p) - pivot is exactly zero and which passes the sign test whenever the window does.  A non-positive sample makes the sums
+    // NaN / -inf, and tail_bad discards them.
+    const float x_p = wv(P.tail.from) - blmean;
+    const float pv_tl = __builtin_amdgcn_logf(x_p);
     if (tid == 0) S.misc[MS_PVTL] = pv_tl;
     // ---- tailstats sums of log(x), x = x' - delta (src/tailstats.jl:22-72), reduced at once (a loop of its own, before y takes
     // the place of x': the two loops' temporaries do not add up)
@@ -556,21 +631,17 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (row_out(cls_tail, r)) continue;
-        const int i0 = 4 * (opaque(tid) + NT * r);
         f2 v0 = mk2(x[r].x - delta, x[r].y - delta), v1 = mk2(x[r].z - delta, x[r].w - delta);
-        const bool edge = !row_in(cls_tail, r);
-        const int lo = P.tail.from - i0, hi = P.tail.until - i0;
-        if (edge) {   // samples outside the window must not trip the sign test
-          v0.x = in_win(0, lo, (uint32_t)(hi - lo)) ? v0.x : 1.f; v0.y = in_win(1, lo, (uint32_t)(hi - lo)) ? v0.y : 1.f;
-          v1.x = in_win(2, lo, (uint32_t)(hi - lo)) ? v1.x : 1.f; v1.y = in_win(3, lo, (uint32_t)(hi - lo)) ? v1.y : 1.f;
+        if (!row_in(cls_tail, r)) {
+          const int i0 = 4 * (opaque(tid) + NT * r);
+          const int lo = P.tail.from - i0;
+          const uint32_t span = (uint32_t)(P.tail.until - P.tail.from);
+          v0.x = in_win(0, lo, span) ? v0.x : x_p; v0.y = in_win(1, lo, span) ? v0.y : x_p;
+          v1.x = in_win(2, lo, span) ? v1.x : x_p; v1.y = in_win(3, lo, span) ? v1.y : x_p;
         }
         tmin = vmin3(tmin, v0.x, v0.y); tmin = vmin3(tmin, v1.x, v1.y);
-        f2 d0 = mk2(__logf(fmaxf(v0.x, 1e-30f)), __logf(fmaxf(v0.y, 1e-30f))) - pvl;
-        f2 d1 = mk2(__logf(fmaxf(v1.x, 1e-30f)), __logf(fmaxf(v1.y, 1e-30f))) - pvl;
-        if (edge) {
-          d0.x = in_win(0, lo, (uint32_t)(hi - lo)) ? d0.x : 0.f; d0.y = in_win(1, lo, (uint32_t)(hi - lo)) ? d0.y : 0.f;
-          d1.x = in_win(2, lo, (uint32_t)(hi - lo)) ? d1.x : 0.f; d1.y = in_win(3, lo, (uint32_t)(hi - lo)) ? d1.y : 0.f;
-        }
+        const f2 d0 = mk2(__builtin_amdgcn_logf(v0.x), __builtin_amdgcn_logf(v0.y)) - pvl;
+        const f2 d1 = mk2(__builtin_amdgcn_logf(v1.x), __builtin_amdgcn_logf(v1.y)) - pvl;
         wacc_quad(a, d0, d1, r);
       }
       wacc_lane<NT>(a, tid, (float)P.tail.ic, &l1, &l2, &lx);
@@ -581,8 +652,8 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-#if LDSP_L3_TAB0
-    __syncthreads();   // wave 0's tables are in LDS
+#if LDSP_L3_TAB0 && !defined(LDSP_WHATIF_S16)
+    LDSP_BAR_MAIN();   // wave 0's tables are in LDS
 #endif
     // ---- y (registers) and T (-> X) of every quad
     const float c = P.pz_c, cd = c * delta, hc = 0.5f * c;
@@ -592,7 +663,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       const int i0 = 4 * (opaque(tid) + NT * r);
       const float fi = (float)i0;
 #if LDSP_L3_TAB0
-      const float Hr = readlane_f(S.scn[4 * wave + r], 0), Lr = readlane_f(S.scn[R * NW + 4 * wave + r], 0), Br = readlane_f(S.scn[2 * R * NW + 4 * wave + r], 0);   // the row's entries (wave-uniform addresses)
+      const float Hr = S.scn[4 * wave + r], Lr = S.scn[R * NW + 4 * wave + r], Br = S.scn[2 * R * NW + 4 * wave + r];   // the row's entries (wave-uniform addresses: broadcast reads)
 #else
       const float Hr = readlane_f(tab_hi, r * NW + wave), Lr = readlane_f(tab_lo, r * NW + wave), Br = readlane_f(tab_b, r * NW + wave);   // the row's entries
 #endif
@@ -664,13 +735,33 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     for (int r = 0; r < R; ++r) hyl[r * NW + wave + 1] = y[r].w;
   }
   if (tid < 4 * NH) S.hy[4 * NH * R * NW + tid] = 0.f;
-  STAMP(3); DSTOP(3);
-  __syncthreads();   // X = T; halo table, threshold candidates, pivot
+  STAMP(3); DSTOP(3); LDSP_PROBE();
+  LDSP_BAR_MAIN();   // X = T; halo table, threshold candidates, pivot
   // quad j + 1, j + 2, .. of the thread's row (the next lanes' registers; for the last lanes the next wave-row's first quads)
+  // (the table quad is read into the destination registers — a wave-uniform address, every lane receives it — and the DPP moves
+  // overwrite every lane that has a successor: lane 63 keeps the table's value; no select)
   auto halo_next = [&](f4 q, int r, int level) {
-    f4 h = (f4){wave_shl1(q.x), wave_shl1(q.y), wave_shl1(q.z), wave_shl1(q.w)};
-    const f4 t = *reinterpret_cast<const f4*>(&S.hy[4 * (NH * (r * NW + wave + 1) + level)]);
-    if (lane == 63) h = t;
+#ifdef LDSP_WHATIF_S16
+    if (r > 0 || level > 0) return q;
+#endif
+    f4 h = *reinterpret_cast<const f4*>(&S.hy[4 * (NH * (r * NW + wave + 1) + level)]);
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %4 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %1, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %2, %6 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %3, %7 wave_shl:1 row_mask:0xf bank_mask:0xf"
+                 : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+    return h;
+  };
+  auto halo_next2 = [&](f4 q, int r) {   // the first two samples of the next quad (sweep A's short leg)
+#ifdef LDSP_WHATIF_S16
+    if (r > 0) return (f2)q.xy;
+#endif
+    f2 h = *reinterpret_cast<const f2*>(&S.hy[4 * (NH * (r * NW + wave + 1))]);
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %1, %3 wave_shl:1 row_mask:0xf bank_mask:0xf"
+                 : "+v"(h.x), "+v"(h.y) : "v"(q.x), "v"(q.y));
     return h;
   };
 
@@ -683,7 +774,8 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     // from y itself — the thread's quad and the first two samples of the next lane's: on the tail T is 1e7..1e8 and a difference
     // of two of its float values is good to 1..8 counts, the size of the threshold the INVERTED trace is tested against there.
     {
-      const TrapDev t0 = P.t0;
+      TrapDev t0 = P.t0;
+      if (STUDY) { t0.n1 = 2; t0.g = 6; t0.flen = 133; }
       const int nout = L - t0.flen + 1;
       const float thr0 = P.t0_thr * t0.navg, mthr0 = -thr0;
       const int s_b = t0.n1 + t0.g, s_c = t0.flen;
@@ -702,7 +794,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         const f4 tb4 = FAST ? rdq_t<0>(S.X, ic + s_b) : rdq(S.X, ic + s_b, s_b & 3), tc4 = FAST ? rdq_t<1>(S.X, ic + s_c) : rdq(S.X, ic + s_c, s_c & 3);
         f4 sl;
         if (short1) {
-          const f4 hn = halo_next(y[r], r, 0);
+          const f2 hn = halo_next2(y[r], r);
           sl = y[r];
           if (t0.n1 >= 2) sl += (f4){y[r].y, y[r].z, y[r].w, hn.x};
           if (t0.n1 >= 3) sl += (f4){y[r].z, y[r].w, hn.x, hn.y};
@@ -716,12 +808,13 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
           o.x = (i0 + 0 < nout) ? o.x : NAN; o.y = (i0 + 1 < nout) ? o.y : NAN;
           o.z = (i0 + 2 < nout) ? o.z : NAN; o.w = (i0 + 3 < nout) ? o.w : NAN;
         }
-        wp[r] = s4_pack_word(nib_ge(o, thr0), lane);
-        wn[r] = s4_pack_word(nib_le(o, mthr0), lane);   // -trap >= thr
+        wp[r] = nib_ge(o, thr0);
+        wn[r] = nib_le(o, mthr0);   // -trap >= thr
       }
       };
       if ((s_b & 3) == 0 && (s_c & 1) == 1) rows(std::true_type{});
       else rows(std::false_type{});
+      s4_pack4(wp, lane); s4_pack4(wn, lane);
       static_assert(M_T0INV == M_T0 + 1, "mask order");
       if ((lane & 7) == 7) {   // word of (row r, wave, lane group): samples 4 (64 wave + 8 (lane >> 3) + NT r) ..
         uint32_t* bw = S.bm + M_T0 * NWORDS + 8 * wave + (lane >> 3);
@@ -729,36 +822,44 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         for (int r = 0; r < R; ++r) { bw[(NT / 8) * r] = wp[r]; bw[NWORDS + (NT / 8) * r] = wn[r]; }
       }
     }
-    STAMP(4); DSTOP(4);
+    STAMP(4); DSTOP(4); LDSP_PROBE(); LDSP_PROBE();
     // ---- sweep B, LS view: extrema of the three fixed trapezoids, arg-max of the optimised one (dsp_icpc.jl:147-164, 202-204);
     // two rows per step (one ds_read2st64_b32 per shift), packed arithmetic
     const float* tb = &S.X[tid];
     auto rd2 = [&](const float* p, int m) { return mk2(p[NT * m], p[NT * (m + 1)]); };
     // (two trapezoids per pass over the rows — seven address registers and two trapezoids' reads in flight at a time — and T[k]
     // read once more: the register budget of three workgroups per CU)
+    // Row pairs wholly inside both output ranges of a pass (most: one scalar test per pair, straight-line code, no selects, no joins);
+    // the one or two pairs that hold the end of a range run a rolled loop with bounds tests.
     {
       const TrapDev f0 = P.fixed[0], f1 = P.fixed[1];
       const float *f0a = tb + f0.n1, *f0b = tb + f0.n1 + f0.g, *f0c = tb + f0.flen;
       const float *f1a = tb + f1.n1, *f1b = tb + f1.n1 + f1.g, *f1c = tb + f1.flen;
-      const f2 rr0 = splat(f0.rr), rr1 = splat(f1.rr);
+      f2 rr0 = splat(f0.rr), rr1 = splat(f1.rr);
+      if (LDSP_L3_SGC_VGPR) { pin(rr0); pin(rr1); }
       const int n0 = L - f0.flen + 1, n1 = L - f1.flen + 1;
+      const int pfull = min(n0, n1) / (2 * NT), pend = (max(n0, n1) + 2 * NT - 1) / (2 * NT);   // (block-uniform)
 #pragma unroll
       for (int m = 0; m < SP; m += 2) {
-        if (NT * m >= max(n0, n1)) continue;   // pair beyond both output ranges
+        if (m / 2 >= pfull) break;
         const f2 Tk = rd2(tb, m);
         const f2 a0 = rd2(f0a, m), b0 = rd2(f0b, m), c0_ = rd2(f0c, m);
         const f2 a1 = rd2(f1a, m), b1 = rd2(f1b, m), c1_ = rd2(f1c, m);
         const f2 o0 = fma2(c0_ - b0, rr0, Tk - a0), o1 = fma2(c1_ - b1, rr1, Tk - a1);
-        if (NT * (m + 2) <= min(n0, n1)) {   // pair wholly inside both output ranges (most pairs)
-          mx0 = vmax3(mx0, o0.x, o0.y); mn0 = vmin3(mn0, o0.x, o0.y);
-          mx1 = vmax3(mx1, o1.x, o1.y);
-        } else {
-          const int k0 = opaque(tid) + NT * m, k1 = k0 + NT;
-          mx0 = vmax3(mx0, k0 < n0 ? o0.x : -INFINITY, k1 < n0 ? o0.y : -INFINITY);
-          mn0 = vmin3(mn0, k0 < n0 ? o0.x : INFINITY, k1 < n0 ? o0.y : INFINITY);
-          mx1 = vmax3(mx1, k0 < n1 ? o1.x : -INFINITY, k1 < n1 ? o1.y : -INFINITY);
-        }
+        mx0 = vmax3(mx0, o0.x, o0.y); mn0 = vmin3(mn0, o0.x, o0.y);
+        mx1 = vmax3(mx1, o1.x, o1.y);
         __builtin_amdgcn_sched_barrier(0);
+      }
+      for (int pm = pfull; pm < min(pend, SP / 2); ++pm) {
+        const int off = 2 * NT * pm;
+        const int k0 = opaque(tid) + off, k1 = k0 + NT;
+        const f2 Tk = rd2(tb + off, 0);
+        const f2 a0 = rd2(f0a + off, 0), b0 = rd2(f0b + off, 0), c0_ = rd2(f0c + off, 0);
+        const f2 a1 = rd2(f1a + off, 0), b1 = rd2(f1b + off, 0), c1_ = rd2(f1c + off, 0);
+        const f2 o0 = fma2(c0_ - b0, rr0, Tk - a0), o1 = fma2(c1_ - b1, rr1, Tk - a1);
+        mx0 = vmax3(mx0, k0 < n0 ? o0.x : -INFINITY, k1 < n0 ? o0.y : -INFINITY);
+        mn0 = vmin3(mn0, k0 < n0 ? o0.x : INFINITY, k1 < n0 ? o0.y : INFINITY);
+        mx1 = vmax3(mx1, k0 < n1 ? o1.x : -INFINITY, k1 < n1 ? o1.y : -INFINITY);
       }
       mx0 *= f0.inv1; mn0 *= f0.inv1; mx1 *= f1.inv1;
     }
@@ -766,32 +867,44 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       const TrapDev f2_ = P.fixed[2], fo = P.opt;
       const float *f2a = tb + f2_.n1, *f2b = tb + f2_.n1 + f2_.g, *f2c = tb + f2_.flen;
       const float *foa = tb + fo.n1, *fob = tb + fo.n1 + fo.g, *foc = tb + fo.flen;
-      const f2 rr2 = splat(f2_.rr), rro = splat(fo.rr);
+      f2 rr2 = splat(f2_.rr), rro = splat(fo.rr);
+      if (LDSP_L3_SGC_VGPR) { pin(rr2); pin(rro); }
       const int n2 = L - f2_.flen + 1, no = L - fo.flen + 1;
+      const int pfull = min(n2, no) / (2 * NT), pend = (max(n2, no) + 2 * NT - 1) / (2 * NT);
+      // the optimised trapezoid's arg-max is tracked as the ROW of the sample (an inline constant in the straight-line part); the
+      // index follows at the end
 #pragma unroll
       for (int m = 0; m < SP; m += 2) {
-        if (NT * m >= max(n2, no)) continue;
+        if (m / 2 >= pfull) break;
         const f2 Tk = rd2(tb, m);
         const f2 a2 = rd2(f2a, m), b2 = rd2(f2b, m), c2_ = rd2(f2c, m);
         const f2 ao = rd2(foa, m), bo = rd2(fob, m), co = rd2(foc, m);
         const f2 o2 = fma2(c2_ - b2, rr2, Tk - a2);
-        f2 oo = fma2(co - bo, rro, Tk - ao);
-        if (NT * (m + 2) <= min(n2, no)) {
-          mx2 = vmax3(mx2, o2.x, o2.y); mn2 = vmin3(mn2, o2.x, o2.y);
-        } else {
-          const int k0 = opaque(tid) + NT * m, k1 = k0 + NT;
-          mx2 = vmax3(mx2, k0 < n2 ? o2.x : -INFINITY, k1 < n2 ? o2.y : -INFINITY);
-          mn2 = vmin3(mn2, k0 < n2 ? o2.x : INFINITY, k1 < n2 ? o2.y : INFINITY);
-          oo.x = k0 < no ? oo.x : -INFINITY; oo.y = k1 < no ? oo.y : -INFINITY;
-        }
-        if (oo.x > bo_v) { bo_v = oo.x; bo_i = opaque(tid) + NT * m; }
-        if (oo.y > bo_v) { bo_v = oo.y; bo_i = opaque(tid) + NT * (m + 1); }
+        const f2 oo = fma2(co - bo, rro, Tk - ao);
+        mx2 = vmax3(mx2, o2.x, o2.y); mn2 = vmin3(mn2, o2.x, o2.y);
+        if (oo.x > bo_v) { bo_v = oo.x; bo_i = m; }
+        if (oo.y > bo_v) { bo_v = oo.y; bo_i = m + 1; }
         __builtin_amdgcn_sched_barrier(0);
       }
+      for (int pm = pfull; pm < min(pend, SP / 2); ++pm) {
+        const int off = 2 * NT * pm;
+        const int k0 = opaque(tid) + off, k1 = k0 + NT;
+        const f2 Tk = rd2(tb + off, 0);
+        const f2 a2 = rd2(f2a + off, 0), b2 = rd2(f2b + off, 0), c2_ = rd2(f2c + off, 0);
+        const f2 ao = rd2(foa + off, 0), bo = rd2(fob + off, 0), co = rd2(foc + off, 0);
+        const f2 o2 = fma2(c2_ - b2, rr2, Tk - a2);
+        f2 oo = fma2(co - bo, rro, Tk - ao);
+        mx2 = vmax3(mx2, k0 < n2 ? o2.x : -INFINITY, k1 < n2 ? o2.y : -INFINITY);
+        mn2 = vmin3(mn2, k0 < n2 ? o2.x : INFINITY, k1 < n2 ? o2.y : INFINITY);
+        oo.x = k0 < no ? oo.x : -INFINITY; oo.y = k1 < no ? oo.y : -INFINITY;
+        if (oo.x > bo_v) { bo_v = oo.x; bo_i = 2 * pm; }
+        if (oo.y > bo_v) { bo_v = oo.y; bo_i = 2 * pm + 1; }
+      }
+      bo_i = (bo_i != 0x7fffffff) ? opaque(tid) + NT * bo_i : bo_i;
       mx2 *= f2_.inv1; mn2 *= f2_.inv1; bo_v *= fo.inv1;
     }
   }
-  STAMP(5); DSTOP(5);
+  STAMP(5); DSTOP(5); LDSP_PROBE();
   // ---- signalstats of the pole-zero corrected tail (dsp_icpc.jl:122) from the registers, pivot = its first sample
   float t1, t2, tx;
   {
@@ -825,7 +938,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       S.wsum[(W_PZ + 0) * NW + wave] = t1; S.wsum[(W_PZ + 1) * NW + wave] = t2; S.wsum[(W_PZ + 2) * NW + wave] = tx;
     }
   }
-  __syncthreads();   // every read of T is done
+  LDSP_BAR_MAIN();   // every read of T is done
   // ---- Savitzky-Golay derivatives, current maxima (dsp_icpc.jl:181-186): g[k] = sum_i c[i] y[k+i] (valid mode, trailing time
   // axis).  The four outputs of a quad from the M + 3 samples w[0 .. M+2] = the quad and its halo (the next lanes' registers by
   // DPP), one multiply-add per tap and output.  This pass takes the statistics (maximum, baseline sums, current maxima); the
@@ -841,13 +954,19 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       wv_[4 + 4 * j] = h.x; wv_[5 + 4 * j] = h.y; wv_[6 + 4 * j] = h.z; wv_[7 + 4 * j] = h.w;
     }
   };
+  float sgc0[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    sgc0[i] = P.sg_c[0][i];   // zero beyond the filter's own taps (the host zero-fills the block)
+    if (LDSP_L3_SGC_VGPR) asm volatile("" : "+v"(sgc0[i]));
+  }
   auto sg_main = [&](int r, const float (&wv_)[4 + 4 * NH], float (&go)[4]) {   // -inf beyond the output axis
     const int i0 = 4 * (opaque(tid) + NT * r);
 #pragma unroll
     for (int e = 0; e < 4; ++e) go[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
-      const float c = P.sg_c[0][i];   // zero beyond the filter's own taps (the host zero-fills the block)
+      const float c = sgc0[i];
 #pragma unroll
       for (int e = 0; e < 4; ++e) go[e] = fmaf(c, wv_[e + i], go[e]);
     }
@@ -864,8 +983,10 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     const int cw_from[4] = {P.cur_from[0], P.cur_from[1], P.cur_from[2], P.cur_from[3]};
     const uint32_t cw_len[4] = {(uint32_t)(P.cur_until[0] - P.cur_from[0]), (uint32_t)(P.cur_until[1] - P.cur_from[1]),
                                 (uint32_t)(P.cur_until[2] - P.cur_from[2]), (uint32_t)(P.cur_until[3] - P.cur_from[3])};
-    auto track = [&](int f, int k, float gv) {
-      const float gw = ((uint32_t)(k - cw_from[f]) <= cw_len[f]) ? gv : -INFINITY;
+    // (IN: the row lies wholly inside the filter's current window — what rowcls says of most rows that meet it — and the window test
+    // of every sample, a subtraction, a compare and a select, falls away)
+    auto track = [&](int f, int k, float gv, bool in) {
+      const float gw = (in || (uint32_t)(k - cw_from[f]) <= cw_len[f]) ? gv : -INFINITY;
       const bool gt = gw > bv[f];
       bv[f] = gt ? gw : bv[f];
       bi[f] = gt ? k : bi[f];
@@ -889,14 +1010,21 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         for (int e = 0; e < 4; ++e) { g_s1 += dd[e]; g_s2 = fmaf(dd[e], dd[e], g_s2); }
       }
       if (!row_out(cls_cur0, r)) {
+        if (row_in(cls_cur0, r)) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) track(0, i0 + e, go[e]);
+          for (int e = 0; e < 4; ++e) track(0, i0 + e, go[e], true);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) track(0, i0 + e, go[e], false);
+        }
       }
       if (!row_out(cls_curx, r)) {   // SG(60 ns), SG(100 ns), plain derivative: only rows that touch the current window
         // (one filter at a time, its four outputs tracked before the next one's are computed)
+        auto others = [&](auto in_tag) {
+        constexpr bool IN = decltype(in_tag)::value;
 #pragma unroll
         for (int f = 1; f < 3; ++f) {
-          if (f == 2 && P.sg_same_02) continue;
+          if (f == 2 && (STUDY || P.sg_same_02)) continue;
           float gf[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int i = 0; i < M; ++i) {
@@ -905,7 +1033,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
             for (int e = 0; e < 4; ++e) gf[e] = fmaf(c, wv_[e + i], gf[e]);
           }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) track(f, i0 + e, gf[e]);
+          for (int e = 0; e < 4; ++e) track(f, i0 + e, gf[e], IN);
           __builtin_amdgcn_sched_barrier(0);
         }
         // y[k] - y[k-1]: the sample before the quad is the previous lane's last one (lane 0: the previous wave-row's, from the table)
@@ -915,11 +1043,14 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         float g3[4] = {y[r].x - ypv, y[r].y - y[r].x, y[r].z - y[r].y, y[r].w - y[r].z};   // y[k] - y[k-1]
         if (i0 == 0) g3[0] = y[r].y - y[r].x;                                                // y[max(i,1)] - y[max(i-1,0)] at i = 0
 #pragma unroll
-        for (int e = 0; e < 4; ++e) track(3, i0 + e, g3[e]);
+        for (int e = 0; e < 4; ++e) track(3, i0 + e, g3[e], IN);
+        };
+        if (row_in(cls_curi, r)) others(std::true_type{});
+        else others(std::false_type{});
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-  STAMP(6); DSTOP(6);
+  STAMP(6); DSTOP(6); LDSP_PROBE();
   // ---- the SG pass's own reductions
   LDSP_DPP_GROUP3("v_max_f32_dpp", gmax, "v_add_f32_dpp", g_s1, "v_add_f32_dpp", g_s2);
   {
@@ -939,7 +1070,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   }
   }
   STAMP(7); DSTOP(7);
-  __syncthreads();   // the round's results are posted
+  LDSP_BAR_MAIN();   // the round's results are posted
   STAMP(8); DSTOP(8);
 
   // ================================================================== round 3: the masks of the SG output (own quads of X); y -> X
@@ -959,8 +1090,9 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const f4 gq = *reinterpret_cast<const f4*>(&S.X[4 * (tid + NT * r)]);
-      wi[r] = s4_pack_word(nib_ge(gq, thr_intr), lane); w5[r] = s4_pack_word(nib_ge(gq, thr_sg50), lane);
+      wi[r] = nib_ge(gq, thr_intr); w5[r] = nib_ge(gq, thr_sg50);
     }
+    s4_pack4(wi, lane); s4_pack4(w5, lane);
     // y -> X (each thread overwrites the quads it has just read)
 #pragma unroll
     for (int r = 0; r < R; ++r) *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = y[r];
@@ -973,7 +1105,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     }
   }
   STAMP(9); DSTOP(9);
-  __syncthreads();   // X = y and the four masks are complete
+  LDSP_BAR_MAIN();   // X = y and the four masks are complete
   STAMP(10); DSTOP(10);
 
   // ================================================================== round 4: run scans on the masks, threshold confirmation
@@ -994,7 +1126,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   };
   // Intersect scans on the bit-masks (thread <-> word), see icpc_lean.hip
   static_assert(2 * NWORDS == NT, "one t0 / inverted-t0 word per thread");
-  if (P.t0_mintot <= 97 && P.intrace_mintot <= 32) {   // block-uniform
+  if (STUDY || (P.t0_mintot <= 97 && P.intrace_mintot <= 32)) {   // block-uniform
     const int q = tid / NWORDS, wd = tid % NWORDS;
     const uint32_t* b0 = S.bm + (M_T0 + q) * NWORDS;
     const bool has_i = tid < NWORDS;
@@ -1053,7 +1185,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       ok = p_tx >= 1 && p_tx + P.tx_mintot <= L;
       for (int j = 1; ok && j < P.tx_mintot; ++j) ok = S.X[p_tx + j] >= thrq;
     }
-    if (__ballot(lane < 5 && !ok) != 0ull) {   // block-uniform
+    if (!STUDY && __ballot(lane < 5 && !ok) != 0ull) {   // block-uniform
       __syncthreads();
       if (tid < 5) S.sl->imin[IM_TX0 + tid] = 0x7fffffff;
       for (int m = 0; m < SP; ++m) {
@@ -1076,7 +1208,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     }
   }
   STAMP(11); DSTOP(11);
-  __syncthreads();
+  LDSP_BAR_MAIN();
   STAMP(12); DSTOP(12);
 
   // ================================================================== round 5: crossings, estimators, finishing lanes
@@ -1117,7 +1249,8 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     if (S.sl->isum[IS_TAILBAD] == 0) {
       float s1 = 0.f, s2 = 0.f, sx = 0.f, sl, of;
       for (int ww = 0; ww < NW; ++ww) { s1 += S.wsum[(W_TAIL + 0) * NW + ww]; s2 += S.wsum[(W_TAIL + 1) * NW + ww]; sx += S.wsum[(W_TAIL + 2) * NW + ww]; }
-      win_finish(s1, s2, sx, P.tail, S.misc[MS_PVTL], P.t_first, P.dt, &tail_mean, &tail_sigma, &sl, &of);
+      constexpr float LN2 = 0.693147180559945309f;   // the sums and their pivot are in log2 units
+      win_finish(s1 * LN2, s2 * (LN2 * LN2), sx * LN2, P.tail, S.misc[MS_PVTL] * LN2, P.t_first, P.dt, &tail_mean, &tail_sigma, &sl, &of);
       tail_tau = -__builtin_amdgcn_rcpf(sl);
     }
     S.outv[C_tail_tau] = tail_tau; S.outv[C_tail_mean] = tail_mean; S.outv[C_tail_sigma] = tail_sigma;
@@ -1280,7 +1413,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   }
   {
     lds_float* eslot = S.misc + 4;
-    __syncthreads();   // every read of X = y is done
+    LDSP_BAR_MAIN();   // every read of X = y is done
     if (tid == 0) {
       S.outv[C_e_trap] = eslot[0];
       S.outv[C_qdrift] = eslot[1];
@@ -1333,7 +1466,11 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       float p0[R], tt[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) { const f2 t = y[r].xy + y[r].zw; tt[r] = t.x + t.y; p0[r] = tt[r]; }
+#ifdef LDSP_WHATIF_S16
+      LDSP_DPP_GROUP1("v_add_f32_dpp", p0[0]);
+#else
       LDSP_DPP_GROUP4("v_add_f32_dpp", p0[0], "v_add_f32_dpp", p0[1], "v_add_f32_dpp", p0[2], "v_add_f32_dpp", p0[3]);
+#endif
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const float fs = (float)wrow(r);
@@ -1348,16 +1485,17 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     for (int i = tid; i < pad; i += NT) S.X[i - pad] = 0.f;   // the gap (dead mask words) becomes Dp[i < 0] = 0
     if (tid < 64) S.X[Lp + tid] = 0.f;
     store_dp();
-    __syncthreads();
-    STAMP(16); DSTOP(16);
+    LDSP_BAR_CZ();
+    STAMP(16); DSTOP(16); LDSP_PROBE(); LDSP_PROBE();
     f2 ac[SP / 2];
     // ---- flat top + last tap (LS).  The last tap multiplies y'[k] = Dp'[k] + (y0 - cpiv) - eps T'[k]; the host admits this kernel
     // only where eps * |w_last| * (rail * L) is far below the columns' resolution (dsp_icpc sets tau = 1e7 us "to switch off CR",
     // src/dsp_icpc.jl:98: eps = 1.6e-9) and the third term is dropped.
     auto flat_top = [&]() {
-      const f2 wl = splat(Z.w_last), sc = splat(Z.sc);
+      f2 wl = splat(Z.w_last), sc = splat(Z.sc);
       const float yc = y0 - cpiv;
-      const f2 wlc = splat(Z.w_last * yc);
+      f2 wlc = splat(Z.w_last * yc);
+      if (LDSP_L3_SGC_VGPR) { pin(wl); pin(sc); pin(wlc); }
       const float *dk = &S.X[tid], *dpa = &S.X[tid + Lf - 1 - lt], *dpb = &S.X[tid + Lf - 1 - f1];
 #pragma unroll
       for (int m = 0; m < SP; m += 2) {
@@ -1383,9 +1521,12 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         const int32_t* cs = fold ? ZZ.zf_s : ZZ.zc_s;
         const float* cr = fold ? ZZ.zf_r : ZZ.zc_r;
         // (two halves of the rows in turn: half the chain's registers — previous reads, reads in flight — at a time)
+#ifndef LDSP_L3_UHALVES
+#define LDSP_L3_UHALVES 2   // the rows in two halves: half the chain's registers at a time (1: one pass, 15 registers spill)
+#endif
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          constexpr int HP = SP / 4;   // row pairs per half
+        for (int hf = 0; hf < LDSP_L3_UHALVES; ++hf) {
+          constexpr int HP = SP / (2 * LDSP_L3_UHALVES);   // row pairs per part
           f2 prev[HP];
           {
             const float* dp = &S.X[tid - cs[0]];
@@ -1393,7 +1534,8 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
             for (int m = 0; m < HP; ++m) prev[m] = rd2(dp, 2 * (HP * hf + m));
           }
           auto link = [&](int e) {
-            const f2 ce = splat(cr[e]);
+            f2 ce = splat(cr[e]);
+            if (LDSP_L3_SGC_VGPR) pin(ce);
             const float* dq = &S.X[tid - cs[e + 1]];
 #pragma unroll
             for (int m = 0; m < HP; ++m) {
@@ -1402,7 +1544,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
               prev[m] = cur;
             }
           };
-          if (nch == 9) {   // (block-uniform) the usual tap structure: links unrolled
+          if (STUDY || nch == 9) {   // (block-uniform) the usual tap structure: links unrolled
 #pragma unroll
             for (int e = 0; e < 8; ++e) link(e);
           } else {
@@ -1411,13 +1553,13 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
           __builtin_amdgcn_sched_barrier(0);
         }
         flat_top();   // (after the chain: its sixteen accumulators are not alive across it)
-        __syncthreads();   // every read of Dp is done
+        LDSP_BAR_CZ();   // every read of Dp is done
 #pragma unroll
         for (int m = 0; m < SP; m += 2) wr2(&S.X[tid], m, u[m / 2]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the compiler does not count the stores of an asm statement)
       }
-      __syncthreads();
-      STAMP(17); DSTOP(17);
+      LDSP_BAR_CZ();
+      STAMP(17); DSTOP(17); LDSP_PROBE(); LDSP_PROBE();
       // ---- PRF = cumsum(cumsum(u)) (S4).  Two levels: inside a wave-row (256 samples) the single and double running sums l1, l2
       // start from zero and stay in float; the state entering each wave-row, (C1, C2), is carried in double:
       //   c2[j] = C2 + (j+1)*C1 + l2[j],  C1' = C1 + l1[255],  C2' = C2 + 256*C1 + l2[255].   Each thread rewrites its own quads.
@@ -1431,10 +1573,18 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
           i1[r] = p3[r];
           i2[r] = (q0 + q1_) + (q2_ + p3[r]);   // the quad's own contribution to the double sum
         }
+#ifdef LDSP_WHATIF_S16
+        LDSP_DPP_GROUP1("v_add_f32_dpp", i1[0]);
+#else
         LDSP_DPP_GROUP4("v_add_f32_dpp", i1[0], "v_add_f32_dpp", i1[1], "v_add_f32_dpp", i1[2], "v_add_f32_dpp", i1[3]);
+#endif
 #pragma unroll
         for (int r = 0; r < R; ++r) { ex1[r] = i1[r] - p3[r]; i2[r] = fmaf(4.f, ex1[r], i2[r]); ex2[r] = i2[r]; }
+#ifdef LDSP_WHATIF_S16
+        LDSP_DPP_GROUP1("v_add_f32_dpp", i2[0]);
+#else
         LDSP_DPP_GROUP4("v_add_f32_dpp", i2[0], "v_add_f32_dpp", i2[1], "v_add_f32_dpp", i2[2], "v_add_f32_dpp", i2[3]);
+#endif
 #pragma unroll
         for (int r = 0; r < R; ++r) ex2[r] = i2[r] - ex2[r];
         double* pa = S.dpart; double* pb = S.dpart + R * NW;
@@ -1442,7 +1592,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
 #pragma unroll
           for (int r = 0; r < R; ++r) { pa[r * NW + wave] = (double)i1[r]; pb[r * NW + wave] = (double)i2[r]; }
         }
-        __syncthreads();
+        LDSP_BAR_CZ();
         const double t1 = (lane < R * NW) ? pa[lane] : 0.0;
         const double c1x = wave_incl_scan_sum_f64(t1) - t1;
         const double t2 = (lane < R * NW) ? pb[lane] + 256.0 * c1x : 0.0;
@@ -1466,7 +1616,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
           *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = (f4){va.x, va.y, vb.x, vb.y};
         }
       }
-      __syncthreads();
+      LDSP_BAR_CZ();
       {
         const float* pr = &S.X[tid + Lf - 1];
 #pragma unroll
@@ -1516,10 +1666,11 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = (f4){g0, g1, g2, g3};
       }
     }
-    __syncthreads();
+    LDSP_BAR_CZ();
     {
       const float *gn = &S.X[tid + Lf - 1], *gnl = &S.X[tid + Lf - 1 - lt], *gk = &S.X[tid], *gkl = &S.X[tid + ltp - 1];
-      const f2 qlt = splat(Z.q_lt), qml = splat(Z.q_mltp), ql1 = splat(Z.q_ltp1), sh = splat(Z.sc_half_den);
+      f2 qlt = splat(Z.q_lt), qml = splat(Z.q_mltp), ql1 = splat(Z.q_ltp1), sh = splat(Z.sc_half_den);
+      if (LDSP_L3_SGC_VGPR) { pin(qlt); pin(qml); pin(ql1); pin(sh); }   // (vector registers: no scalar source in the loop's instructions)
 #pragma unroll
       for (int m = 0; m < SP; m += 2) {
         if (NT * m >= nout) continue;
@@ -1530,7 +1681,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         if ((m & 2) == 2) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    STAMP(20); DSTOP(20);
+    STAMP(20); DSTOP(20); LDSP_PROBE(); LDSP_PROBE();
     // ---- anti-causal one-pole A -> X, rise(+) and fall(-) exponentials
     {
       float b[R], s_in[R];
@@ -1550,10 +1701,11 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       }
       if (tid == 0) S.X[Lp] = 0.f;   // A[L]
     }
-    __syncthreads();
+    LDSP_BAR_CZ();
     {
       const float *a1 = &S.X[tid + Lf - lt], *a2 = &S.X[tid + Lf], *a3 = &S.X[tid + 1], *a4 = &S.X[tid + ltp];
-      const f2 qm1 = splat(Z.q_mlt1), qq1 = splat(Z.q1), qq2 = splat(Z.q2), ql1 = splat(Z.q_ltp1), sh = splat(Z.sc_half_den);
+      f2 qm1 = splat(Z.q_mlt1), qq1 = splat(Z.q1), qq2 = splat(Z.q2), ql1 = splat(Z.q_ltp1), sh = splat(Z.sc_half_den);
+      if (LDSP_L3_SGC_VGPR) { pin(qm1); pin(qq1); pin(qq2); pin(ql1); pin(sh); }
 #pragma unroll
       for (int m = 0; m < SP; m += 2) {
         if (NT * m >= nout) continue;
@@ -1565,7 +1717,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         if ((m & 2) == 2) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    STAMP(21); DSTOP(21);
+    STAMP(21); DSTOP(21); LDSP_PROBE(); LDSP_PROBE();
     // ---- extremestats + SignalEstimator of both outputs (dsp_icpc.jl:170-171,177-178): value first, then its first index
     const int tqf = opaque(tid);
     float mxc = -INFINITY, mxz = -INFINITY;
@@ -1605,7 +1757,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         if (WZ) { S.wsum[(W_CZ + 1) * NW + wave] = pz_; atomicMax(&S.sl->fmx[FX_ZAC], ford(mxz)); }
       }
     }
-    __syncthreads();
+    LDSP_BAR_CZ();
     {
       const float vc = ford_inv(S.sl->fmx[FX_CUSP]), vz = ford_inv(S.sl->fmx[FX_ZAC]);
       if (__ballot((WC && own_c == vc) || (WZ && own_z == vz)) != 0ull) {   // only the waves that hold a maximum look its index up
@@ -1622,7 +1774,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       }
     }
     STAMP(22); DSTOP(22);
-    __syncthreads();
+    LDSP_BAR_CZ();
     if (tid < 2 && (tid == 0 ? WC : WZ)) {
       const int f = tid;
       float s = 0.f;
@@ -1642,14 +1794,14 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   } else {
     const float cp_c = S.misc[12], cp_z = S.misc[13];
     cz_pass(T_{}, F_{}, P.cusp, P.zac, cp_c);
-    __syncthreads();   // every read of A is done
+    LDSP_BAR_CZ();   // every read of A is done
 #pragma unroll
     for (int r = 0; r < R; ++r) y[r] = ysave[r];
     cz_pass(F_{}, T_{}, P.zac, P.zac, cp_z);
   }
   STAMP(23); DSTOP(23);
   // ------------------------------------------------------------------------------------------------ outputs
-  __syncthreads();   // the output row was filled by lanes of different waves
+  LDSP_BAR_MAIN();   // the output row was filled by lanes of different waves
   static_assert(C_NCOLS <= 64, "the output row is stored by wave 0");
   if (tid < C_NCOLS) {
     float* dst = reinterpret_cast<float*>(out.col[tid]);

@@ -128,12 +128,21 @@ int ldsp_ctx_destroy(ldsp_ctx* c) {
 // The context's workspaces (filter tables, slabs, the two-kernel scratch) are reused by every launch: work queued on the
 // previous stream may still be reading them when the first launch on the new stream overwrites them.  A change of stream
 // therefore orders the new stream behind everything queued on the old one (event + stream wait, no host synchronisation).
+// The previous stream may no longer be usable when the caller switches (destroyed by its owner, or being captured): then the
+// ordering event cannot be recorded on it.  The context must still leave it — otherwise every later call fails the same way —,
+// so the error is cleared, the device is synchronised instead (everything that could still read the workspaces has finished),
+// and the new stream is adopted.
 static int switch_stream(ldsp_ctx* c, hipStream_t next) {
   if (next == c->stream) return LDSP_OK;
-  HIP_TRY(hipEventRecord(c->evs, c->stream));
-  HIP_TRY(hipStreamWaitEvent(next, c->evs, 0));
+  ldsp_device_guard guard(c->device);
+  bool ordered = hipEventRecord(c->evs, c->stream) == hipSuccess && hipStreamWaitEvent(next, c->evs, 0) == hipSuccess;
+  if (!ordered) {
+    (void)hipGetLastError();
+    ordered = hipDeviceSynchronize() == hipSuccess;
+    if (!ordered) (void)hipGetLastError();
+  }
   c->stream = next;
-  return LDSP_OK;
+  return ordered ? LDSP_OK : fail(LDSP_ERR_HIP, "stream change: neither an event on the previous stream nor a device synchronisation succeeded (new stream adopted)");
 }
 
 int ldsp_ctx_set_stream(ldsp_ctx* c, void* s) {
@@ -420,8 +429,9 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, int r2, Ic
   d.cusp_mode = (cusp_direct || !cz_ok) ? 0 : 1;  // unexpected kernel structure -> direct-form comparator
   {
     const int wlo = std::min(std::min(d.cur_from[1], d.cur_from[2]), d.cur_from[3]), whi = std::max(std::max(d.cur_until[1], d.cur_until[2]), d.cur_until[3]);
-    const int win[5][2] = {{d.bl.from, d.bl.until}, {d.tail.from, d.tail.until}, {d.sgbl.from, d.sgbl.until}, {d.cur_from[0], d.cur_until[0]}, {wlo, whi}};
-    for (int w = 0; w < 5; ++w)
+    const int ilo = std::max(std::max(d.cur_from[1], d.cur_from[2]), d.cur_from[3]), ihi = std::min(std::min(d.cur_until[1], d.cur_until[2]), d.cur_until[3]);
+    const int win[6][2] = {{d.bl.from, d.bl.until}, {d.tail.from, d.tail.until}, {d.sgbl.from, d.sgbl.until}, {d.cur_from[0], d.cur_until[0]}, {wlo, whi}, {ilo, ihi}};
+    for (int w = 0; w < 6; ++w)
       for (int v = 0; v < 16; ++v) {
         uint32_t m = 0;
         for (int r = 0; r < 4; ++r) {

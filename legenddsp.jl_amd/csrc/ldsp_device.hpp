@@ -19,6 +19,11 @@
 #include "wave_prims.hpp"
 #include "run_scan.hpp"
 
+#ifdef LDSP_WHATIF_NOBAR_CZ   // (timing experiment, icpc_lean3.hip)
+#define LDSP_BAR_SCAN() ((void)0)
+#else
+#define LDSP_BAR_SCAN() __syncthreads()
+#endif
 namespace ldsp {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -67,12 +72,17 @@ __device__ __forceinline__ void s4_exscan_affine_fwd(const float (&b)[R], float 
   const float f15 = qp4[(l & 15) + 1], f31 = qp4[(l & 31) + 1], fl = qp4[l];
   float inc[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) inc[r] = wave_incl_scan_affine(b[r], P, f15, f31);
+  for (int r = 0; r < R; ++r) {
+#ifdef LDSP_WHATIF_S16
+    if (r > 0) { inc[r] = b[r]; continue; }
+#endif
+    inc[r] = wave_incl_scan_affine(b[r], P, f15, f31);
+  }
   if (l == 63) {
 #pragma unroll
     for (int r = 0; r < R; ++r) part[r * NW + w] = inc[r];
   }
-  __syncthreads();
+  LDSP_BAR_SCAN();
   // scan of the wave-row end states with decay q^256 per step
   const AffinePow PW = {qpw[1], qpw[2], qpw[4], qpw[8]};
   const float pv = (l < R * NW) ? part[l] : 0.f;
@@ -95,12 +105,17 @@ __device__ __forceinline__ void s4_exscan_affine_bwd(const float (&b)[R], float 
   const float fl = qp4[63 - l], frow = qp4[16 - (l & 15)], a16 = qp4[16];
   float inc[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) inc[r] = wave_incl_scan_affine_rev(b[r], P, a16, frow);
+  for (int r = 0; r < R; ++r) {
+#ifdef LDSP_WHATIF_S16
+    if (r > 0) { inc[r] = b[r]; continue; }
+#endif
+    inc[r] = wave_incl_scan_affine_rev(b[r], P, a16, frow);
+  }
   if (l == 0) {
 #pragma unroll
     for (int r = 0; r < R; ++r) part[r * NW + w] = inc[r];
   }
-  __syncthreads();
+  LDSP_BAR_SCAN();
   // mirrored order: lane j holds the wave-row (R*NW-1-j), scanned forward with decay q^256
   constexpr int NP = R * NW;
   const AffinePow PW = {qpw[1], qpw[2], qpw[4], qpw[8]};

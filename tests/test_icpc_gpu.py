@@ -314,6 +314,91 @@ def test_traces_shorter_than_the_tile(orc, length, kernel, sep):
             assert np.array_equal(a[c], b[c]) and (c != "n_sat_high" or np.all(a[c] >= 5)), c
 
 
+def test_context_changes_stream_and_can_leave_a_destroyed_one(params):
+    """ldsp_ctx_set_stream (include/ldsp.h, lifetime rule): run on stream A, switch to B (ordered behind A by an event), destroy A's
+    successor while the context still points at it, and switch again — the context must adopt the new stream (device
+    synchronisation in place of the event) instead of failing on the dead one for ever; the tables are the same every time."""
+    wf = ldsp.synth.hpge_batch(64, L, device="cuda", seed=5)
+    torch.cuda.synchronize()                         # (the batch is complete before another stream reads it)
+    ctx = ldsp.Context(0, use_torch_stream=False)   # (the context launches where set_stream says, not on torch's current stream)
+    ref = ldsp.icpc_run(wf, params, ctx).clone()
+    ctx.synchronize()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    for st in (a, b):
+        st.wait_stream(torch.cuda.current_stream())
+        ctx.set_stream(st.cuda_stream)
+        with torch.cuda.stream(st):
+            t = ldsp.icpc_run(wf, params, ctx)
+        st.synchronize()
+        assert torch.equal(t.view(torch.int32), ref.view(torch.int32))
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    raw = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(raw)) == 0
+    ctx.set_stream(raw.value)
+    t = ldsp.icpc_run(wf, params, ctx)
+    ctx.synchronize()
+    assert torch.equal(t.view(torch.int32), ref.view(torch.int32))
+    assert hip.hipStreamDestroy(raw) == 0            # the context still points at it
+    ctx.set_stream(b.cuda_stream)                    # must succeed (or report once) and adopt b
+    with torch.cuda.stream(b):
+        t = ldsp.icpc_run(wf, params, ctx)
+    b.synchronize()
+    assert torch.equal(t.view(torch.int32), ref.view(torch.int32))
+    ctx.use_own_stream()
+    t = ldsp.icpc_run(wf, params, ctx)
+    ctx.synchronize()
+    assert torch.equal(t.view(torch.int32), ref.view(torch.int32))
+
+
+def _scaled_config(length, dt, degree2):
+    """The reference test configuration with every window scaled onto a trace of `length` samples at `dt` ns (the fixed filters keep
+    their times; at dt >= 32 ns the 60 ns Savitzky-Golay window and the 100 ns estimator cannot carry a cubic: degree 2, as
+    plumbing_icpc_config_4096 does)."""
+    import dataclasses
+    us = ldsp.us
+    sc = length * dt / (8192 * 16.0)
+    cfg = ldsp.plumbing_icpc_config_4096() if degree2 else ldsp.reference_test_icpc_config()
+    return dataclasses.replace(cfg, bl_window=ldsp.ClosedInterval(0.0, 39.0 * us * sc),
+                               tail_window=ldsp.ClosedInterval(70.0 * us * sc, min(110.0 * us * sc, (length - 1) * dt)),
+                               current_window=ldsp.ClosedInterval(43.0 * us * sc, 62.0 * us * sc),
+                               enc_pickoff_trap=40.0 * us * sc, enc_pickoff_zac=41.0 * us * sc, enc_pickoff_cusp=41.0 * us * sc,
+                               flt_length_cusp=38.0 * us * sc, flt_length_zac=38.0 * us * sc), sc
+
+
+@pytest.mark.parametrize("length,dt,u16,sep", [(2048, 16.0, False, False), (1024, 32.0, False, False),      # full tiles of 128 / 64 threads
+                                                 (4096, 32.0, False, True),                                   # 256 threads, CUSP and ZAC separate
+                                                 (3000, 16.0, False, False), (1500, 16.0, True, False),       # short tiles of 256 / 128 threads (uint16 input)
+                                                 (900, 32.0, False, True), (1800, 16.0, True, True)])         # short tiles of 64 / 128 threads, separate CUSP / ZAC
+def test_small_tiles_run_the_lean_kernel(orc, length, dt, u16, sep):
+    """Every instantiation the launcher admits (ldsp_api.hip: icpc_lean_applies) is compared with the oracle by name: tiles of 64, 128
+    and 256 threads (L = 1024, 2048, 4096), full and shorter than the tile, float32 and uint16 input, shared and separately optimised
+    CUSP / ZAC — and with the generic kernel on the same batch.  (Round 3 tested the 512-thread tile only; the round-2 advisor had found
+    exactly this class of untested instantiation broken in the previous kernel.)"""
+    us = ldsp.us
+    cfg, sc = _scaled_config(length, dt, degree2=dt >= 32.0)
+    pf = {"cusp": {"rt": 4.0 * us * sc, "ft": 1.5 * us * sc}, "zac": {"rt": 5.5 * us * sc, "ft": 2.0 * us * sc}} if sep else {}
+    pf["trap"] = {"rt": 5.0 * us * sc, "ft": 2.5 * us * sc}
+    p = ldsp.lower_icpc(cfg, 500 * us, pf, length, 0.0, dt)
+    n = 128
+    wf = ldsp.synth.hpge_batch(n, 8192, device="cuda", seed=71)
+    idx = (torch.arange(length, device="cuda", dtype=torch.float32) * (8192.0 / length)).long().clamp(max=8191)
+    wf = wf[:, idx].contiguous()                     # the 8192-sample shapes resampled onto `length` samples
+    if u16:
+        wf = wf.round().clamp(0, 65535)
+    host = wf.cpu().numpy()
+    ora = orc.dsp_icpc(host, p, nthreads=16)
+    ctx = ldsp.default_context()
+    gpu = _run(wf.to(torch.uint16) if u16 else wf, p)
+    assert ctx.last_kernel_name() == "lean3::icpc_lean3_kernel"
+    lines, worst = parity.compare(gpu, ora, wf=host, params=p, orc=orc)
+    assert worst <= 2 / n, "\n".join(l for l in lines if f"bad=0/{n}" not in l)
+    gen = _run(wf, p, generic=1)
+    assert ctx.last_kernel_name() == "icpc_kernel"
+    for c in parity.INT_COLS:
+        assert (np.abs(gpu[c].astype(np.int64) - gen[c].astype(np.int64)) > 0).sum() <= 2, c
+
+
 def test_separately_optimised_cusp_and_zac_run_in_the_lean_launch(orc):
     """pars_filter with different rise / flat-top times for CUSP and ZAC (what an optimisation campaign produces): the lean
     kernel evaluates the two filters in two passes of its closed-form stage inside the SAME launch (y kept in registers for

@@ -9,7 +9,7 @@ TAG=$1; shift
 CS=legenddsp.jl_amd/csrc
 make -s -C $CS ldsp_api.o functor_kernels.o sipm_kernel.o
 mkdir -p build/dev
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -Wno-unused-variable -Wno-unused-function -DLDSP_DEV_512"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -Wno-unused-variable -Wno-unused-function -DLDSP_DEV_512 -mllvm -amdgpu-atomic-optimizer-strategy=None"
 newer() { [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ $CS/icpc_dev.hpp -nt "$2" ] || [ $CS/ldsp_device.hpp -nt "$2" ] || [ $CS/wave_prims.hpp -nt "$2" ]; }
 if [ "${LDSP_DEV_GENERIC:-0}" = 1 ] || newer $CS/icpc_kernel.hip build/dev/icpc_generic.o; then
   /opt/rocm/bin/hipcc $FLAGS -c $CS/icpc_kernel.hip -o build/dev/icpc_generic.o &

@@ -3,7 +3,7 @@
 # and a static count of VALU, moves, selects, compares, SALU, LDS.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-variable -Wno-unused-function -DLDSP_DEV_512 "$@" \
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-variable -Wno-unused-function -DLDSP_DEV_512 -mllvm -amdgpu-atomic-optimizer-strategy=None "$@" \
   -S --cuda-device-only $R/legenddsp.jl_amd/csrc/icpc_lean3.hip -o /tmp/l3_all.s 2>/dev/null
 awk '/^_ZN4ldsp5lean317icpc_lean3_kernelILi512ELi7ELb0ELb1EEE[A-Za-z0-9_]*:/{f=1} f{print} f&&/^\.Lfunc_end/{exit}' /tmp/l3_all.s > /tmp/l3_512.s
 awk '/^_ZN4ldsp5lean317icpc_lean3_kernelILi512ELi7ELb0ELb1EEE[A-Za-z0-9_]*:/{f=1} f&&/\.amdhsa_next_free_vgpr|\.amdhsa_next_free_sgpr|private_segment_fixed_size|; ScratchSize|; Occupancy|sgpr_spill|vgpr_spill/{print} f&&/\.end_amdhsa_kernel/{exit}' /tmp/l3_all.s | sort -u | head -8
