@@ -117,6 +117,10 @@ class Env:
         if self.dry:
             self.dev = torch.device("cpu")
         else:
+            ndev = torch.cuda.device_count()     # (counting devices does not initialise one)
+            if not 0 <= self.local_rank < ndev:
+                raise SystemExit(f"bench.py: rank {self.rank} has LOCAL_RANK={self.local_rank} but this process sees {ndev} GPU(s) "
+                                 "(one rank per GPU of ONE node: check --gpus / --nproc-per-node against the visible devices)")
             self.dev = torch.device("cuda", self.local_rank)
             torch.cuda.set_device(self.dev)
         if self.world > 1:

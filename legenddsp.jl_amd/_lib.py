@@ -125,6 +125,12 @@ def lib():
             if not os.path.exists(_SO):
                 raise LdspError(-100, f"{_SO} not found: run __graft_entry__.build() "
                                       "(legenddsp_jl_amd has no CPU fallback)")
+            if os.environ.get("LDSP_HIP_LIB") and not os.environ.get("LDSP_ALLOW_STALE"):
+                # a development build selected by hand: refuse one that is older than the sources it was built from (a stale
+                # diagnostic library once ended a profiling run with an undefined symbol after the minutes had been spent)
+                newest = max((os.path.getmtime(os.path.join(_CSRC, f)) for f in os.listdir(_CSRC) if f.endswith((".hip", ".hpp", ".inc"))), default=0.0)
+                if os.path.getmtime(_SO) < newest:
+                    raise LdspError(-104, f"{_SO} is older than the sources in {_CSRC}: rebuild it (tools/dev_build*.sh) or set LDSP_ALLOW_STALE=1")
             l = C.CDLL(_SO)
             _declare(l)
             if l.ldsp_abi_version() != _abi.LDSP_ABI_VERSION:

@@ -1659,7 +1659,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         gq = fmaf(q1, gq, d[r][1].y);
         b[r] = gq;
       }
-      s4_exscan_affine_fwd<NT, R>(b, s_in, Z.qp4, Z.qpw, S.part);   // barrier inside: the LS reads of Dp are done
+      s4_exscan_affine_fwd<NT, R>(b, s_in, Z.qp4, Z.qpw, S.part);   // (the wave index as a scalar argument, or the four chains in one statement: five / six registers to scratch, -1.6 % / -3 %)   // barrier inside: the LS reads of Dp are done
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const float g0 = fmaf(q1, s_in[r], d[r][0].x), g1 = fmaf(q1, g0, d[r][0].y), g2 = fmaf(q1, g1, d[r][1].x), g3 = fmaf(q1, g2, d[r][1].y);

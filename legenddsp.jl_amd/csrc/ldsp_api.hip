@@ -128,21 +128,14 @@ int ldsp_ctx_destroy(ldsp_ctx* c) {
 // The context's workspaces (filter tables, slabs, the two-kernel scratch) are reused by every launch: work queued on the
 // previous stream may still be reading them when the first launch on the new stream overwrites them.  A change of stream
 // therefore orders the new stream behind everything queued on the old one (event + stream wait, no host synchronisation).
-// The previous stream may no longer be usable when the caller switches (destroyed by its owner, or being captured): then the
-// ordering event cannot be recorded on it.  The context must still leave it — otherwise every later call fails the same way —,
-// so the error is cleared, the device is synchronised instead (everything that could still read the workspaces has finished),
-// and the new stream is adopted.
+// The previous stream is NOT touched: every run call has left an event behind on the stream it used (ldsp_run_guard), and the new
+// stream waits for the latest one — the previous stream may already have been destroyed by its owner.
 static int switch_stream(ldsp_ctx* c, hipStream_t next) {
   if (next == c->stream) return LDSP_OK;
   ldsp_device_guard guard(c->device);
-  bool ordered = hipEventRecord(c->evs, c->stream) == hipSuccess && hipStreamWaitEvent(next, c->evs, 0) == hipSuccess;
-  if (!ordered) {
-    (void)hipGetLastError();
-    ordered = hipDeviceSynchronize() == hipSuccess;
-    if (!ordered) (void)hipGetLastError();
-  }
-  c->stream = next;
-  return ordered ? LDSP_OK : fail(LDSP_ERR_HIP, "stream change: neither an event on the previous stream nor a device synchronisation succeeded (new stream adopted)");
+  c->stream = next;   // adopted whatever happens below
+  if (c->evs_recorded) HIP_TRY(hipStreamWaitEvent(next, c->evs, 0));
+  return LDSP_OK;
 }
 
 int ldsp_ctx_set_stream(ldsp_ctx* c, void* s) {
@@ -520,7 +513,7 @@ int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_
   if (n < 0 || n > 0x7fffffffLL) return fail(LDSP_ERR_INVALID_ARG, "n = %lld out of range", (long long)n);
   if (n == 0) return LDSP_OK;
   if (!wf) return fail(LDSP_ERR_INVALID_ARG, "waveform pointer is NULL");
-  ldsp_device_guard guard(c->device);
+  ldsp_run_guard guard(c);
   int rc = prepare_icpc(c, p, in_u16);
   if (rc) return rc;
   IcpcOutDev od;
@@ -560,7 +553,7 @@ static int pz_trap_run_impl(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_
   if (n < 0 || n > 0x7fffffffLL) return fail(LDSP_ERR_INVALID_ARG, "n = %lld out of range", (long long)n);
   if (n == 0) return LDSP_OK;
   if (!wf) return fail(LDSP_ERR_INVALID_ARG, "waveform pointer is NULL");
-  ldsp_device_guard guard(c->device);
+  ldsp_run_guard guard(c);
   int rc = prepare_icpc(c, p, in_u16);   // (the kernels read in_u16 from the parameter block)
   if (rc) return rc;
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));

@@ -65,9 +65,27 @@ struct ldsp_ctx {
   // timing
   int timing = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evm = nullptr;  // evm: boundary between the two dsp_icpc kernels
-  hipEvent_t evs = nullptr;                                 // orders a newly set stream behind the previous one
+  hipEvent_t evs = nullptr;                                 // recorded at the end of every run call on the stream that ran it: a newly set stream waits for it
+  bool evs_recorded = false;
   int n_launches = 0, n_stages = 1;
   const char* last_kernel = "";   // dominant kernel of the last ldsp_*_run call (static string)
+};
+
+// Scope of one run call: the context's device is current, and at the end — however the call returns — an event is recorded on the
+// stream the call used.  A later change of stream (ldsp_ctx_set_stream) makes the new stream wait for that event and never touches the
+// previous stream again: its owner may have destroyed it in the meantime (hipEventRecord on a destroyed stream does not fail, it crashes).
+struct ldsp_run_guard {
+  ldsp_device_guard dev;
+  ldsp_ctx* c;
+  explicit ldsp_run_guard(ldsp_ctx* ctx) : dev(ctx ? ctx->device : -1), c(ctx) {}
+  ~ldsp_run_guard() {
+    if (c && c->evs) {
+      if (hipEventRecord(c->evs, c->stream) == hipSuccess) c->evs_recorded = true;
+      else (void)hipGetLastError();
+    }
+  }
+  ldsp_run_guard(const ldsp_run_guard&) = delete;
+  ldsp_run_guard& operator=(const ldsp_run_guard&) = delete;
 };
 
 // common argument checks of the per-trace entry points
@@ -76,4 +94,4 @@ int ldsp_check_batch(ldsp_ctx* c, const void* x, int64_t n, int32_t L, const cha
 // Argument checks common to the batch entry points, then the context's device made current for the rest of the CALLER's scope
 // (restored at its exit).  Used as a statement:  int rc = ldsp_check_batch(c, x, n, L, "name");
 int ldsp_check_batch_impl(ldsp_ctx* c, const void* x, int64_t n, int32_t L, const char* who);
-#define ldsp_check_batch(c, x, n, L, who) ldsp_check_batch_impl((c), (x), (n), (L), (who)); ldsp_device_guard ldsp_guard_((c) ? (c)->device : -1)
+#define ldsp_check_batch(c, x, n, L, who) ldsp_check_batch_impl((c), (x), (n), (L), (who)); ldsp_run_guard ldsp_guard_((c))

@@ -19,6 +19,9 @@
 #include "wave_prims.hpp"
 #include "run_scan.hpp"
 
+#ifndef LDSP_AFFINE_GROUPED   // 1: the four chains of an affine scan in one asm statement (no s_nop per step; in icpc_lean3_kernel the statement's
+#define LDSP_AFFINE_GROUPED 0  // seven simultaneous registers push six values into scratch: measured before it is made the default)
+#endif
 #ifdef LDSP_WHATIF_NOBAR_CZ   // (timing experiment, icpc_lean3.hip)
 #define LDSP_BAR_SCAN() ((void)0)
 #else
@@ -63,20 +66,23 @@ __device__ __forceinline__ void s4_exscan_sum(const T (&tot)[R], double (&off)[R
 // each of the thread's chunks, forward direction (state 0 before chunk 0).
 // b[r]: the chunk's own end state from zero input state.
 // qp4[j] = q^(4j), j = 0..64;  qpw[j] = q^(256j), j = 0..64 (one wave-row = 256 samples).
+// (w: the wave index; a caller that holds it in a scalar register passes it — as a lane-select operand a vector value costs a
+// v_readfirstlane and four wait states per use)
 template <int NT, int R>
 __device__ __forceinline__ void s4_exscan_affine_fwd(const float (&b)[R], float (&s_in)[R], const float* qp4, const float* qpw,
-                                                     float* part) {
+                                                     float* part, int w = wave_id()) {
   constexpr int NW = NT / 64;
-  const int w = wave_id(), l = lane_id();
+  const int l = lane_id();
   const AffinePow P = {qp4[1], qp4[2], qp4[4], qp4[8]};
   const float f15 = qp4[(l & 15) + 1], f31 = qp4[(l & 31) + 1], fl = qp4[l];
   float inc[R];
+  if constexpr (R == 4 && LDSP_AFFINE_GROUPED) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-#ifdef LDSP_WHATIF_S16
-    if (r > 0) { inc[r] = b[r]; continue; }
-#endif
-    inc[r] = wave_incl_scan_affine(b[r], P, f15, f31);
+    for (int r = 0; r < R; ++r) inc[r] = b[r];
+    wave_incl_scan_affine4(inc, P, f15, f31);
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) inc[r] = wave_incl_scan_affine(b[r], P, f15, f31);
   }
   if (l == 63) {
 #pragma unroll
@@ -98,18 +104,19 @@ __device__ __forceinline__ void s4_exscan_affine_fwd(const float (&b)[R], float 
 // Anti-causal mirror: state entering each chunk from the RIGHT (state 0 after the last chunk).
 template <int NT, int R>
 __device__ __forceinline__ void s4_exscan_affine_bwd(const float (&b)[R], float (&s_in)[R], const float* qp4, const float* qpw,
-                                                     float* part) {
+                                                     float* part, int w = wave_id()) {
   constexpr int NW = NT / 64;
-  const int w = wave_id(), l = lane_id();
+  const int l = lane_id();
   const AffinePow P = {qp4[1], qp4[2], qp4[4], qp4[8]};
   const float fl = qp4[63 - l], frow = qp4[16 - (l & 15)], a16 = qp4[16];
   float inc[R];
+  if constexpr (R == 4 && LDSP_AFFINE_GROUPED) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-#ifdef LDSP_WHATIF_S16
-    if (r > 0) { inc[r] = b[r]; continue; }
-#endif
-    inc[r] = wave_incl_scan_affine_rev(b[r], P, a16, frow);
+    for (int r = 0; r < R; ++r) inc[r] = b[r];
+    wave_incl_scan_affine_rev4(inc, P, a16, frow);
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) inc[r] = wave_incl_scan_affine_rev(b[r], P, a16, frow);
   }
   if (l == 0) {
 #pragma unroll

@@ -147,6 +147,38 @@ __device__ __forceinline__ float wave_incl_scan_affine_rev(float v, const Affine
   const float sel = (row == 0) ? t1 : (row == 1) ? t2 : (row == 2) ? s3 : 0.f;
   return fmaf(frow, sel, v);
 }
+// The same for FOUR independent chains in one asm statement (as LDSP_DPP_GROUP4 below: the other chains fill the two wait states
+// between a step's write and the next step's DPP read of the same register, so no s_nop per step).  The four in-row multipliers are
+// wave-uniform: they arrive in scalar registers and pass through ONE temporary vector register (a DPP instruction takes no scalar
+// source), so the statement holds seven vector registers, not ten.
+#define LDSP_AFF4_STEP(CTL, M) "v_fmac_f32_dpp %0, %0, " M " " CTL "\n\tv_fmac_f32_dpp %1, %1, " M " " CTL "\n\tv_fmac_f32_dpp %2, %2, " M " " CTL "\n\tv_fmac_f32_dpp %3, %3, " M " " CTL "\n\t"
+__device__ __forceinline__ void wave_incl_scan_affine4(float (&v)[4], const AffinePow& P, float f15, float f31) {
+  float tmp;
+  asm volatile("v_mov_b32 %4, %5\n\ts_nop 0\n\t" LDSP_AFF4_STEP("row_shr:1 row_mask:0xf bank_mask:0xf", "%4")
+               "v_mov_b32 %4, %6\n\t" LDSP_AFF4_STEP("row_shr:2 row_mask:0xf bank_mask:0xf", "%4")
+               "v_mov_b32 %4, %7\n\t" LDSP_AFF4_STEP("row_shr:4 row_mask:0xf bank_mask:0xf", "%4")
+               "v_mov_b32 %4, %8\n\t" LDSP_AFF4_STEP("row_shr:8 row_mask:0xf bank_mask:0xf", "%4")
+               LDSP_AFF4_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf", "%9") LDSP_AFF4_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf", "%10")
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "=&v"(tmp) : "s"(P.p1), "s"(P.p2), "s"(P.p4), "s"(P.p8), "v"(f15), "v"(f31));
+}
+// anti-causal: the four in-row steps of four chains in one statement; the row heads are folded as in wave_incl_scan_affine_rev
+__device__ __forceinline__ void wave_incl_scan_affine_rev4(float (&v)[4], const AffinePow& P, float a16, float frow) {
+  float tmp;
+  asm volatile("v_mov_b32 %4, %5\n\ts_nop 0\n\t" LDSP_AFF4_STEP("row_shl:1 row_mask:0xf bank_mask:0xf", "%4")
+               "v_mov_b32 %4, %6\n\t" LDSP_AFF4_STEP("row_shl:2 row_mask:0xf bank_mask:0xf", "%4")
+               "v_mov_b32 %4, %7\n\t" LDSP_AFF4_STEP("row_shl:4 row_mask:0xf bank_mask:0xf", "%4")
+               "v_mov_b32 %4, %8\n\t" LDSP_AFF4_STEP("row_shl:8 row_mask:0xf bank_mask:0xf", "%4")
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "=&v"(tmp) : "s"(P.p1), "s"(P.p2), "s"(P.p4), "s"(P.p8));
+  const int row = (threadIdx.x & 63) >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float s1 = readlane_f(v[r], 16), s2 = readlane_f(v[r], 32), s3 = readlane_f(v[r], 48);
+    const float t2 = fmaf(a16, s3, s2), t1 = fmaf(a16, t2, s1);
+    const float sel = (row == 0) ? t1 : (row == 1) ? t2 : (row == 2) ? s3 : 0.f;
+    v[r] = fmaf(frow, sel, v[r]);
+  }
+}
+#undef LDSP_AFF4_STEP
 // value of lane l+1 (0 for lane 63) / lane l-1 (0 for lane 0)
 __device__ __forceinline__ float wave_shl1(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));

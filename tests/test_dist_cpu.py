@@ -240,3 +240,31 @@ def test_bench_launcher_relays_failure():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "nope"],
                        capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("workload", ["icpc", "sipm"])
+def test_bench_rehearsal_at_the_real_width(workload):
+    """The width the driver's scaling run uses: eight ranks of one node, self-launched (`python bench.py --gpus 8`), both workloads —
+    launcher, process group, contiguous shards, the table gather and (sipm) the ragged gather with its count / scan / payload passes
+    (src/dsp_sipm.jl:149-156 are the ragged columns that travel), on CPU tensors."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--n", "203", "--steps", "2", "--warmup", "1",
+                        "--workload", workload], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["dry_run"] is True and rec["gather_ok"] is True
+
+
+def test_bench_rejects_a_local_rank_without_a_device():
+    """LOCAL_RANK is the device index: a rank whose LOCAL_RANK has no GPU behind it (here: a box without GPUs) stops with a message
+    that names both numbers instead of failing inside set_device."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "MASTER_PORT")}, LOCAL_RANK="3", HIP_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-secondary", "--cpu-sample", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "LOCAL_RANK=3" in (r.stderr + r.stdout), (r.returncode, r.stderr[-500:])

@@ -42,5 +42,5 @@ def test_sipm_randomised_configuration(orc, it):
     sc, trig = ldsp.sipm_run(wf, p)
     torch.cuda.synchronize()
     ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=16)
-    msgs = fuzz_cases.sipm_compare(sc, trig, ora, n)
+    msgs = fuzz_cases.sipm_compare(sc, trig, ora, n, wf, p, orc)
     assert not msgs, descr + ": " + "; ".join(msgs)

@@ -9,8 +9,15 @@ pytestmark = pytest.mark.gpu
 TRIG_FIELDS = ("x", "x_high", "x_tot", "max")
 
 
-def _compare(sc, trig, ora, n, atol_time=0.01):   # ns; positions are Float64 slabs (measured: <= 0.004 ns, tools/sipm_pos_check.py)
-    bad = 0
+def _compare(sc, trig, ora, n, wf=None, p=None, orc=None):
+    """Rows of the batch that differ from the oracle in a way float32 storage of the signals does NOT explain.
+    Scalar columns: every row beyond its tolerance counts (no percentage is waved through).  Trigger groups (tests/sipm_budget.py):
+    positions are held to 0.01 ns, or — on a shallow crossing — to what half an ulp of the stored float32 samples moves the
+    interpolated crossing by, evaluated per trigger from the float64 restatement of the chain; a row whose trigger COUNT differs is a
+    `flip` when a sample of that restatement lies between / at the two thresholds (one crossing more or less), else a defect.
+    Returns (defects, flips): defects must be zero, flips are bounded by the caller as a row count."""
+    import sipm_budget
+    bad_rows = set()
     for i, c in enumerate(ldsp._abi.SIPM_SCALAR_COLS):
         a, b = sc[i].cpu().numpy().astype(np.float64), ora[c]
         tol = 5e-4 + 2e-5 * np.abs(b) if c.startswith(("e_", "thr", "bl", "wf")) else 1e-3
@@ -19,17 +26,18 @@ def _compare(sc, trig, ora, n, atol_time=0.01):   # ns; positions are Float64 sl
         if c in ("wfmean", "wfsigma", "wfoffset", "blmean", "bloffset", "blsigma"):
             tol = 2e-3 + 1e-4 * np.abs(b)
         m = ~(np.abs(a - b) <= tol) & ~(np.isnan(a) & np.isnan(b))
-        assert m.sum() <= max(1, n // 100), (c, a[m][:4], b[m][:4])
-    for g in ldsp._abi.SIPM_TRIG_GROUPS:
-        cg, co = trig[g]["count"].cpu().numpy(), ora[g]["count"]
-        same = cg == co
-        bad += int((~same).sum())
-        for f in TRIG_FIELDS:
-            a, b = trig[g][f].cpu().numpy().astype(np.float64), ora[g][f]
-            tol = atol_time if f != "max" else 1e-3 + 1e-4 * np.abs(np.nan_to_num(b))
-            ok = (np.abs(a - b) <= tol) | (np.isnan(a) & np.isnan(b))
-            bad += int((~ok[same]).any(axis=1).sum())
-    return bad
+        assert m.sum() <= 1, (c, np.nonzero(m)[0][:8], a[m][:4], b[m][:4])     # one row per column at most, and it counts
+        bad_rows |= set(np.nonzero(m)[0].tolist())
+    assert wf is not None, "the budgets need the traces"
+    host = wf.cpu().numpy() if hasattr(wf, "cpu") else np.asarray(wf)
+    res = sipm_budget.compare_triggers(trig, ora, host.astype(np.float32), p, orc, sc_gpu=[x.cpu().numpy() for x in sc], scalar_cols=ldsp._abi.SIPM_SCALAR_COLS)
+    flips = set()
+    for g, r in res.items():
+        assert not r["count_defects"], (g, "trigger count differs with no sample at the threshold", r["count_defects"][:8])
+        assert not r["positions"], (g, "position beyond the float32-storage budget", r["positions"][:8])
+        assert not r["maxima"], (g, "maximum", r["maxima"][:8])
+        flips |= set(r["flips"])
+    return len(bad_rows), len(flips)
 
 
 def test_sipm_matches_oracle(orc):
@@ -40,8 +48,8 @@ def test_sipm_matches_oracle(orc):
     torch.cuda.synchronize()
     ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=16)
     assert int(trig["trig"]["count"].sum()) > n        # the synthetic batch does trigger
-    bad = _compare(sc, trig, ora, n)
-    assert bad <= 4, f"{bad} of {n} traces differ (a row count, not a fraction: 3 on this batch — one trigger more or less where a crossing lies within float32 resolution of n_sigma x threshold)"
+    bad, flips = _compare(sc, trig, ora, n, wf, p, orc)
+    assert bad == 0 and flips <= 3, f"{bad} rows with a scalar beyond tolerance, {flips} of {n} with one trigger more or less at a sample that lies AT the threshold"
 
 
 def test_sipm_same_discharge_bounds_for_both_pipelines(orc):
@@ -61,9 +69,9 @@ def test_sipm_same_discharge_bounds_for_both_pipelines(orc):
     ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=16)
     cols = ldsp._abi.SIPM_SCALAR_COLS
     assert torch.equal(sc[cols.index("threshold_DC")], sc[cols.index("threshold_DC_trap")])
-    # rows, of 128: 2 .. 4 on this batch depending on the last bit of the noise samples — the 32 discharge traces put several
-    # crossings within float32 resolution of n_sigma x threshold, each worth one trigger more or less in one group
-    assert _compare(sc, trig, ora, n) <= 6
+    # (rows of 128 whose trigger count differs by a crossing that lies AT the threshold: the 32 discharge traces put several there)
+    bad, flips = _compare(sc, trig, ora, n, wf, p, orc)
+    assert bad == 0 and flips <= 3, (bad, flips)
 
 
 def test_sipm_reference_fixture_properties():
@@ -108,7 +116,8 @@ def test_sipm_matches_oracle_odd_length(orc, L):
     wf = ldsp.synth.sipm_batch(n, L, device="cuda", seed=9)
     sc, trig = ldsp.sipm_run(wf, p)
     ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=8)
-    assert _compare(sc, trig, ora, n) <= 1
+    bad, flips = _compare(sc, trig, ora, n, wf, p, orc)
+    assert bad + flips <= 1, (bad, flips)
 
 
 @pytest.mark.parametrize("L,dt", [(4096, 16.0), (8192, 16.0)])
@@ -119,7 +128,8 @@ def test_sipm_register_kernel_other_tiles(orc, L, dt):
     wf = ldsp.synth.sipm_batch(n, L, device="cuda", seed=21 + L)
     sc, trig = ldsp.sipm_run(wf, p)
     ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=8)
-    assert _compare(sc, trig, ora, n) <= 1
+    bad, flips = _compare(sc, trig, ora, n, wf, p, orc)
+    assert bad + flips <= 1, (bad, flips)
 
 
 def test_sipm_quantised_and_degenerate_traces(orc):
@@ -132,7 +142,9 @@ def test_sipm_quantised_and_degenerate_traces(orc):
     wf[8:12] = torch.round(wf[8:12])              # steps of 1
     wf[12] = 0.5                                    # constant
     wf[13] = 100.0 * wf[13]                         # almost everything outside the MAD windows
-    ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=8)
+    import sipm_budget
+    host = wf.cpu().numpy()
+    ora = orc.dsp_sipm(host, p, nthreads=8)
     ctx = ldsp.default_context()
     thr_of = {}
     for generic in (0, 1):
@@ -144,10 +156,15 @@ def test_sipm_quantised_and_degenerate_traces(orc):
             i = ldsp._abi.SIPM_SCALAR_COLS.index(c)
             a, b = sc[i].cpu().numpy().astype(np.float64), ora[c]
             tol = 2e-3 + 1e-4 * np.abs(b)
-            # row 13 (trace x 100): few samples are left inside the MAD window, neighbouring order statistics lie ~1e-2 apart, and
-            # ONE sample whose float32 value falls on the other side of the window bound than its float64 value moves the median
-            # by such a gap (the two kernels — different selection algorithms — agree with each other, checked below)
-            tol[13] = 1e-2 * np.abs(b[13])
+            # row 13 (trace x 100): few samples are left inside the MAD window and neighbouring order statistics lie far apart; ONE sample
+            # whose float32 value falls on the other side of the window bound than its float64 value moves both medians by one rank.
+            # The allowance is that spacing, measured on the float64 restatement of THIS trace (tests/sipm_budget.py), not a
+            # percentage (the two kernels — different selection algorithms — agree with each other, checked below)
+            grp, lo, hi = sipm_budget.threshold_window(c, p)
+            sig13, _ = sipm_budget.group_signal(grp, sipm_budget.signals64(host[13], p, orc), p)
+            gap13 = sipm_budget.mad_gap_tolerance(sig13, lo, hi)
+            assert np.isfinite(gap13) and gap13 <= 0.05 * max(abs(b[13]), 1e-3), (c, gap13, b[13])   # (an allowance, not a blank cheque)
+            tol[13] = max(tol[13], gap13)
             ok = (np.abs(a - b) <= tol) | (np.isnan(a) & np.isnan(b))
             assert ok.all(), (generic, c, a[~ok], b[~ok])
             thr_of.setdefault(c, []).append(a)
