@@ -153,8 +153,21 @@ class Env:
             self.dist.destroy_process_group()
 
 
+PREWARM_S = 0.15   # untimed launches in front of the W warm-up steps, see timed()
+
+
 def timed(env, args, step, finish=lambda: None):
-    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.
+    In front of the W warm-up steps the step is repeated (untimed) until 150 ms have passed: after an idle period — the CPU-baseline leg
+    of the previous workload takes seconds — this GPU takes tens of milliseconds of back-to-back work to return to its full clocks, and
+    W = 2 launches of a 6 ms kernel are over before it has (profiles/r04_pz_trap_launch_spread.txt: 24 launches back to back 5.68–5.79 ms,
+    each behind 20 ms of idle 6.8–7.2 ms; round 3's unexplained 5.6–6.7 ms spread of config 2)."""
+    if not env.dry and env.world == 1:   # (one rank only: a time-based count would differ between ranks, and a step of N > 1 holds a collective)
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < PREWARM_S:
+            step()
+            finish()
+            env.sync()
     for _ in range(args.warmup):
         step()
     finish()
@@ -167,13 +180,17 @@ def timed(env, args, step, finish=lambda: None):
     return env.max_over_ranks(time.perf_counter() - t0)
 
 
-# Compute-issue ceilings of the full dsp_icpc chain at L = 8192 (waveforms/s per GPU):
-#   "algorithmic": the minimum arithmetic of the restructured chain (~85 VALU operations per sample) at the measured issue costs
-#   (profiles/r03_micro_issue_costs.txt), perfectly packed, no LDS or barrier time;
-#   "instruction_stream": the VALU time of the instructions icpc_lean3_kernel actually issues, from the hardware counter:
-#   SQ_ACTIVE_INST_VALU = 3 747 quad-cycles per wave (profiles/r03_lean3_valu_mix.txt; 3 690 instructions at 4.07 cycles on average —
-#   46 % of them moves / selects / compares / DPP), 8 waves per trace, 1 024 SIMDs at 2.4 GHz: 2.4e9 * 1024 / (8 * 3747 * 4).
-ISSUE_CEILING_ICPC = {"algorithmic": 65.0e6, "instruction_stream": 20.5e6}
+# Instruction-issue ceilings of the full dsp_icpc chain at L = 8192 (waveforms/s per GPU).  Round 4 measured what
+# binds the kernel: instruction ISSUE of every kind (profiles/r04_lean3_whatif.txt: 832 extra v_fmac per wave cost 1.8 cycles each, 832
+# extra s_add 2.0, 208 extra ds_read_b32 4.5 — their full price, nothing hides; removing all twelve barriers of the CUSP / ZAC stage buys
+# 2.6 %), and that SQ_ACTIVE_INST_VALU — round 3's "VALU 90 % busy" — is an instruction count (profiles/r04_micro_valu_cost.txt).
+#   "algorithmic": the minimum arithmetic of the restructured chain (~85 VALU operations per sample), perfectly packed at 2 cycles per
+#   instruction and SIMD, no scalar, LDS or barrier time;
+#   "instruction_stream": every instruction the shipped kernel issues (SQ_INSTS per wave, all kinds, profiles/r04_lean3_phase_insts.txt)
+#   at the cheapest issue price measured on this chip (2.08 cycles per instruction and SIMD, v_fmac at >= 4 waves per SIMD):
+#   2.4e9 * 1024 SIMDs / (8 waves * INSTS_PER_WAVE * 2.08).  The kernel cannot exceed it without issuing fewer instructions.
+INSTS_PER_WAVE_ICPC = 5940
+ISSUE_CEILING_ICPC = {"algorithmic": 65.0e6, "instruction_stream": 2.4e9 * 1024 / (8 * INSTS_PER_WAVE_ICPC * 2.08)}
 
 
 def roofline(achieved_gbs, kernel, kernel_ms, bytes_per_trace, traffic, issue_of=None):
@@ -200,8 +217,12 @@ def bench_icpc(env, args, n, L, workload, wf=None, pars_filter=None, label=None)
     ncol = 48
     if not env.dry:
         import legenddsp_jl_amd as ldsp
-        dt = 16.0 * (8192 / L) if L < 8192 else 16.0  # 4096-sample plumbing config needs 32 ns
-        cfg = ldsp.reference_test_icpc_config() if L >= 8192 else ldsp.plumbing_icpc_config_4096()
+        # the reference configuration's windows end at 110 us = sample 6875 at 16 ns: every trace of >= 7000 samples runs it unchanged;
+        # shorter traces are sampled more coarsely and take the degree-2 plumbing configuration (4096 samples at 32 ns)
+        ref_cfg = L >= 7000
+        dt = 16.0 if ref_cfg else 16.0 * (8192 / L)
+        cfg = ldsp.reference_test_icpc_config() if ref_cfg else ldsp.plumbing_icpc_config_4096()
+        cfg_name = "reference test/test_dsp_icpc.jl:50-161" if ref_cfg else "plumbing_icpc_config_4096 (reference configuration with sg_flt_degree = int_interpolation_order = 2)"
         params = ldsp.lower_icpc(cfg, 500 * ldsp.us, pars_filter or {}, L, 0.0, dt)
         if wf is None:   # synthetic input, generated directly in HBM (excluded from timing)
             wf = torch.empty((n, L), dtype=torch.float32, device=dev)
@@ -210,7 +231,7 @@ def bench_icpc(env, args, n, L, workload, wf=None, pars_filter=None, label=None)
         ctx.enable_timing(True)
         ncol = len(ldsp._abi.ICPC_COLS)
     else:
-        dt = 16.0
+        dt, cfg_name = 16.0, "dry run"
     out = torch.empty((n, ncol), dtype=torch.float32, device=dev) if workload == "icpc" else \
         torch.empty((2, n), dtype=torch.float32, device=dev)
 
@@ -306,7 +327,7 @@ def bench_icpc(env, args, n, L, workload, wf=None, pars_filter=None, label=None)
             "config": {"workload": (f"BASELINE config {3 if world == 1 else 4}: {n}{' per GPU' if world > 1 else ''} x {L} f32, full dsp_icpc chain"
                                     if workload == "icpc" else f"BASELINE config 2: {n} x {L} f32, pole-zero + trapezoid"),
                        "traces_per_gpu": n, "samples": L, "dt_ns": dt,
-                       "dsp_config": "reference test/test_dsp_icpc.jl:50-161", "tau_us": 500,
+                       "dsp_config": cfg_name, "tau_us": 500,
                        "gather": "rccl gather of [n,48] f32 to rank 0, overlapped with the next batch's kernel (double-buffered)" if pipe else "none"},
             "roofline": roofline(achieved, dom_kernel, dom_ms, bytes_per_trace, measured_traffic(dom_kernel, n, L),
                                  issue_of=(n / (dom_ms * 1e-3)) if (workload == "icpc" and L == 8192) else None),
@@ -366,7 +387,8 @@ def cpu_baseline(args, wf, params, n):
         "cusp_zac_form": best, "forms": legs,
         "single_thread": legs[best]["single_thread"],
         "sample": f"first {m} traces of the same batch (one core: first {m1}), float64 CPU restatement (oracle/ldsp_oracle.c) structured like the "
-                  f"reference's broadcasts, OpenMP over traces; 2375-tap CUSP / ZAC by direct convolution and by FFT, the faster one reported; "
+                  f"reference's broadcasts, OpenMP over traces; 2375-tap CUSP / ZAC by direct convolution and by FFT (complex radix-2 transform of length 16384 — not a real-input FFT "
+                  f"—, the taps' transform computed once per thread and parameter set), the faster one reported; "
                   f"proxy for the single-threaded Julia reference (not runnable here: no Julia), measured, not extrapolated",
     }
 

@@ -67,7 +67,8 @@
         asm volatile("s_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %0, %0, 1" : "+s"(ps_)); } \
   } while (0)
 namespace ldsp {
-extern int g_dbg_lds_pad;   // option "dbg_lds_pad" (defined in icpc_lean.hip)
+extern int g_dbg_lds_pad;   // option "dbg_lds_pad" (defined in icpc_lean.hip): a profiling aid (tools/occ_probe.py), process-global — it inflates the LDS
+                            // request of EVERY context's launches, after the admission check: a pad beyond the CU's LDS makes the launch fail with a HIP error
 namespace lean3 {
 
 typedef __attribute__((address_space(3))) float lds_float;
@@ -394,10 +395,12 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
 #else
   constexpr bool STUDY = false;
 #endif
-  // Trace length: the tile (Lp = 16 NT samples) or less (L % 4 == 0, the host admits nothing else).  Lanes whose quad lies beyond
-  // L load the trace's last quad once more: real sample values, so the raw extremes are unchanged; every filter of the chain is
+  // Trace length: the tile (Lp = 16 NT samples) or less (L % 4 == 0, the host admits nothing else).  A lane whose quad of row 2 or 3
+  // lies beyond L keeps a COPY OF ITS OWN ROW-0 QUAD there (rows 0 and 1 always lie inside the trace: the tile is the smallest that
+  // holds it): real sample values, so the raw extremes are unchanged, and no load address is clamped; every filter of the chain is
   // causal up to its own output range, every output range is bounded by L below (nout, ng, the crossing tests), and the one
-  // anti-causal recursion (CUSP / ZAC) runs on a difference signal that is set to zero beyond L.
+  // anti-causal recursion (CUSP / ZAC) runs on a difference signal that is set to zero beyond L.  (in_trace() below serves only the
+  // rare re-read of the raw samples by the saturation count.)
   const int L = FULL ? Lp : P.L;
   auto in_trace = [&](int i4) { return FULL ? i4 : min(i4, L - 4); };   // offset of a quad, or of the last one
   const int tid = threadIdx.x, lane = tid & 63;
@@ -545,8 +548,18 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   float blmean, raw_max, raw_min, delta;
   {
     const float s = fold_partials<NW>(S.wred, 0.f, [](float a, float b) { return a + b; });
-    const float mx = fold_partials<NW>(S.wred + 3 * NW, -INFINITY, [](float a, float b) { return vmax(a, b); });
-    const float mn = fold_partials<NW>(S.wred + 4 * NW, INFINITY, [](float a, float b) { return vmin(a, b); });
+    float mx, mn;
+    if constexpr (NW == 8) {   // eight partials: four three-operand instructions in ONE statement (a chain of eight asm statements pays a wait state after each)
+      const auto a = *(const lds_f4*)(S.wred + 3 * NW), b = *(const lds_f4*)(S.wred + 3 * NW + 4);
+      const auto c = *(const lds_f4*)(S.wred + 4 * NW), d = *(const lds_f4*)(S.wred + 4 * NW + 4);
+      asm("v_max3_f32 %0, %2, %3, %4\n\tv_min3_f32 %1, %10, %11, %12\n\tv_max3_f32 %0, %0, %5, %6\n\tv_min3_f32 %1, %1, %13, %14\n\t"
+          "v_max3_f32 %0, %0, %7, %8\n\tv_min3_f32 %1, %1, %15, %16\n\tv_max_f32 %0, %0, %9\n\tv_min_f32 %1, %1, %17"
+          : "=&v"(mx), "=&v"(mn)
+          : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w), "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
+    } else {
+      mx = fold_partials<NW>(S.wred + 3 * NW, -INFINITY, [](float a, float b) { return vmax(a, b); });
+      mn = fold_partials<NW>(S.wred + 4 * NW, INFINITY, [](float a, float b) { return vmin(a, b); });
+    }
     delta = s * (float)P.bl.inv_n;
     blmean = fmaf(s, (float)P.bl.inv_n, pv_bl);   // (the statement of pz_trap_lean_kernel, icpc_lean.hip: config 2 reports the same bits)
     if (!STUDY && ext_bl) { blmean = ext_bl[blockIdx.x] * ext_bl_scale; delta = blmean - pv_bl; }   // windowed traces of dsp_icpc_compressed (dsp_icpc.jl:353)

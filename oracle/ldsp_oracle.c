@@ -500,16 +500,38 @@ static void fft_c2(double* re, double* im, int n, int inverse) {   /* in place, 
   }
   if (inverse) { const double s = 1.0 / n; for (int i = 0; i < n; ++i) { re[i] *= s; im[i] *= s; } }
 }
+/* The taps' transform is computed once per parameter set and thread, not once per trace: a small per-thread cache keyed by the tap
+ * array (pointer, length, transform size and a checksum of the values) — what any FFT implementation of a fixed filter does. */
+#define FIR_FFT_SLOTS 4
+typedef struct { const double* h; int m, N; double sum; double* H; } fir_fft_slot;
+static __thread fir_fft_slot g_fft_cache[FIR_FFT_SLOTS];
+static __thread int g_fft_next = 0;
+static const double* fir_fft_taps(const double* h, int m, int N) {
+  double sum = 0.0;
+  for (int j = 0; j < m; ++j) sum += h[j] * (double)(1 + (j & 7));
+  for (int s = 0; s < FIR_FFT_SLOTS; ++s)
+    if (g_fft_cache[s].H && g_fft_cache[s].h == h && g_fft_cache[s].m == m && g_fft_cache[s].N == N && g_fft_cache[s].sum == sum) return g_fft_cache[s].H;
+  fir_fft_slot* c = &g_fft_cache[g_fft_next];
+  g_fft_next = (g_fft_next + 1) % FIR_FFT_SLOTS;
+  free(c->H);
+  c->H = (double*)malloc(sizeof(double) * 2 * (size_t)N);
+  if (!c->H) return NULL;
+  for (int i = 0; i < N; ++i) { c->H[i] = i < m ? h[i] : 0.0; c->H[N + i] = 0.0; }
+  fft_c2(c->H, c->H + N, N, 0);
+  c->h = h; c->m = m; c->N = N; c->sum = sum;
+  return c->H;
+}
 static int fir_fft(const real* x, int n, const double* h, int m, real* y) {
   const int nout = n - m + 1;
   int N = 1;
   while (N < n + m - 1) N <<= 1;
-  double* buf = (double*)malloc(sizeof(double) * 4 * (size_t)N);
-  if (!buf) return ORC_ERR_ARG;
-  double *xr = buf, *xi = buf + N, *hr = buf + 2 * N, *hi = buf + 3 * N;
-  for (int i = 0; i < N; ++i) { xr[i] = i < n ? (double)x[i] : 0.0; xi[i] = 0.0; hr[i] = i < m ? h[i] : 0.0; hi[i] = 0.0; }
+  const double* H = fir_fft_taps(h, m, N);
+  double* buf = (double*)malloc(sizeof(double) * 2 * (size_t)N);
+  if (!buf || !H) { free(buf); return ORC_ERR_ARG; }
+  double *xr = buf, *xi = buf + N;
+  const double *hr = H, *hi = H + N;
+  for (int i = 0; i < N; ++i) { xr[i] = i < n ? (double)x[i] : 0.0; xi[i] = 0.0; }
   fft_c2(xr, xi, N, 0);
-  fft_c2(hr, hi, N, 0);
   for (int i = 0; i < N; ++i) { const double a = xr[i] * hr[i] - xi[i] * hi[i], b2 = xr[i] * hi[i] + xi[i] * hr[i]; xr[i] = a; xi[i] = b2; }
   fft_c2(xr, xi, N, 1);
   for (int k = 0; k < nout; ++k) y[k] = (real)xr[k + m - 1];   /* full convolution index k + m - 1 = valid-mode output k */

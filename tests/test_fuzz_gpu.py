@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 SEED = 1
 
 
-# L = 6000 / 7300 (ragged tiles, generic kernel), 8192 and 16384 (full tiles: the lean kernel when CUSP and ZAC share their
-# geometry — (1, 5), (1, 10) — the generic one otherwise); (2, 1) and (2, 5): noise-free traces with a 13-tap SG window, where
+# L = 6000 / 7300 (traces shorter than the 8192 tile with 16-byte rows: the lean kernel's bounded instantiation, shared or separate
+# CUSP / ZAC geometry), 8192 (full tile: the lean kernel) and 16384 (the generic kernel); (2, 1) and (2, 5): noise-free traces with a 13-tap SG window, where
 # the in-trace pile-up threshold sits on the rounding residue of the baseline (tests/parity.py, inTrace columns)
 @pytest.mark.parametrize("seed,it", [(1, 0), (1, 2), (1, 4), (1, 5), (1, 8), (1, 9), (1, 10), (1, 13), (2, 1), (2, 5)])
 def test_icpc_randomised_configuration(orc, seed, it):

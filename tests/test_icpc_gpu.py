@@ -277,8 +277,8 @@ def test_threshold_crossings_with_spikes_before_the_pulse(orc, params):
                                                 (8190, "icpc_kernel", False), (7301, "icpc_kernel", False)])
 def test_traces_shorter_than_the_tile(orc, length, kernel, sep):
     """A trace that does not fill the tile (16 x threads samples) still runs the fused lean kernel when its rows are 16-byte
-    aligned (length % 4 == 0: quads are loaded whole; the lanes beyond the trace load its last quad again and every output range
-    is bounded by the length) — 8000-, 7300-, 4400-sample traces; other lengths run icpc_kernel.  Both against the oracle on
+    aligned (length % 4 == 0: quads are loaded whole; a lane whose quad lies beyond the trace keeps a copy of its own row-0 quad
+    and every output range is bounded by the length) — 8000-, 7300-, 4400-sample traces; other lengths run icpc_kernel.  Both against the oracle on
     traces whose pulse, tail and windows reach to the very end of the trace, and the lean kernel against the generic one."""
     sc = length / 8192.0
     dt = 16.0
