@@ -369,6 +369,17 @@ __device__ __forceinline__ uint32_t nib_le(f4 v, float t) {
 #ifndef LDSP_L3_SGC_VGPR
 #define LDSP_L3_SGC_VGPR 0   // (1, measured: taps of the SG pass alone +-0, all loop constants -0.9 %: the copies and three spilled registers cost more) loop constants (filter taps, decay factors) live in vector registers: an instruction with a scalar source issues at 1.5x the cost of one without (tools/micro/valu_cost.hip)
 #endif
+// LDSP_LDS_WAIT_ALL(): every LDS read issued so far has returned.  Placed behind a GROUP of reads, in front of their first use: hipcc
+// then drops its own progressive waits (lgkmcnt(3), (2), (1), (0) — one issue slot each, in a kernel that is bound by instruction issue)
+// because the counter is known to be zero.  -DLDSP_L3_WAITALL=0 restores the progressive waits.
+#ifndef LDSP_L3_WAITALL
+#define LDSP_L3_WAITALL 0   // (measured: 19.42 M against 19.43 M waveforms/s — the progressive waits cost nothing that shows)
+#endif
+#if LDSP_L3_WAITALL
+#define LDSP_LDS_WAIT_ALL() __builtin_amdgcn_s_waitcnt(0xc07f)
+#else
+#define LDSP_LDS_WAIT_ALL() ((void)0)
+#endif
 // LDSP_L3_WPS: minimum waves per SIMD the register allocation is bounded for (6: three 512-thread workgroups per CU, <= 80 VGPRs)
 #ifndef LDSP_L3_WPS
 #define LDSP_L3_WPS 6
@@ -858,6 +869,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         const f2 Tk = rd2(tb, m);
         const f2 a0 = rd2(f0a, m), b0 = rd2(f0b, m), c0_ = rd2(f0c, m);
         const f2 a1 = rd2(f1a, m), b1 = rd2(f1b, m), c1_ = rd2(f1c, m);
+        LDSP_LDS_WAIT_ALL();
         const f2 o0 = fma2(c0_ - b0, rr0, Tk - a0), o1 = fma2(c1_ - b1, rr1, Tk - a1);
         mx0 = vmax3(mx0, o0.x, o0.y); mn0 = vmin3(mn0, o0.x, o0.y);
         mx1 = vmax3(mx1, o1.x, o1.y);
@@ -892,6 +904,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         const f2 Tk = rd2(tb, m);
         const f2 a2 = rd2(f2a, m), b2 = rd2(f2b, m), c2_ = rd2(f2c, m);
         const f2 ao = rd2(foa, m), bo = rd2(fob, m), co = rd2(foc, m);
+        LDSP_LDS_WAIT_ALL();
         const f2 o2 = fma2(c2_ - b2, rr2, Tk - a2);
         const f2 oo = fma2(co - bo, rro, Tk - ao);
         mx2 = vmax3(mx2, o2.x, o2.y); mn2 = vmin3(mn2, o2.x, o2.y);
@@ -1515,6 +1528,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         ac[m / 2] = splat(0.f);
         if (NT * m >= nout) continue;   // row pair beyond the output range (block-uniform)
         const f2 yk = rd2(dk, m), pa = rd2(dpa, m), pb = rd2(dpb, m);
+        LDSP_LDS_WAIT_ALL();
         ac[m / 2] = fma2(sc, pa - pb, fma2(wl, yk, wlc));
         pin(ac[m / 2]);
         if ((m & 2) == 2) __builtin_amdgcn_sched_barrier(0);
@@ -1550,11 +1564,14 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
             f2 ce = splat(cr[e]);
             if (LDSP_L3_SGC_VGPR) pin(ce);
             const float* dq = &S.X[tid - cs[e + 1]];
+            f2 cur[HP];
+#pragma unroll
+            for (int m = 0; m < HP; ++m) cur[m] = rd2(dq, 2 * (HP * hf + m));
+            LDSP_LDS_WAIT_ALL();
 #pragma unroll
             for (int m = 0; m < HP; ++m) {
-              const f2 cur = rd2(dq, 2 * (HP * hf + m));
-              u[HP * hf + m] = fma2(ce, prev[m] - cur, u[HP * hf + m]);
-              prev[m] = cur;
+              u[HP * hf + m] = fma2(ce, prev[m] - cur[m], u[HP * hf + m]);
+              prev[m] = cur[m];
             }
           };
           if (STUDY || nch == 9) {   // (block-uniform) the usual tap structure: links unrolled
@@ -1687,8 +1704,10 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
 #pragma unroll
       for (int m = 0; m < SP; m += 2) {
         if (NT * m >= nout) continue;
-        const f2 pm = rd2(gn, m) - qlt * rd2(gnl, m);
-        const f2 fp = qml * (rd2(gkl, m) - ql1 * rd2(gk, m));
+        const f2 g_n = rd2(gn, m), g_nl = rd2(gnl, m), g_kl = rd2(gkl, m), g_k = rd2(gk, m);
+        LDSP_LDS_WAIT_ALL();
+        const f2 pm = g_n - qlt * g_nl;
+        const f2 fp = qml * (g_kl - ql1 * g_k);
         ac[m / 2] = fma2(sh, fp - pm, ac[m / 2]);
         pin(ac[m / 2]);
         if ((m & 2) == 2) __builtin_amdgcn_sched_barrier(0);
@@ -1722,8 +1741,10 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
 #pragma unroll
       for (int m = 0; m < SP; m += 2) {
         if (NT * m >= nout) continue;
-        const f2 pp = qm1 * rd2(a1, m) - qq1 * rd2(a2, m);
-        const f2 fm = qq2 * (rd2(a3, m) - ql1 * rd2(a4, m));
+        const f2 a_1 = rd2(a1, m), a_2 = rd2(a2, m), a_3 = rd2(a3, m), a_4 = rd2(a4, m);
+        LDSP_LDS_WAIT_ALL();
+        const f2 pp = qm1 * a_1 - qq1 * a_2;
+        const f2 fm = qq2 * (a_3 - ql1 * a_4);
         ac[m / 2] = fma2(sh, pp - fm, ac[m / 2]);
         if constexpr (WZ) dz[m / 2] += ac[m / 2];   // the ZAC output
         pin(ac[m / 2]);
