@@ -391,7 +391,7 @@ __device__ __forceinline__ uint32_t nib_le(f4 v, float t) {
 #define LDSP_L3_RWPS 6
 #endif
 // SEP: CUSP and ZAC have their own geometry (two passes of the closed-form stage); keeps a second copy of y in registers
-// FULL: the trace fills the tile (L = 16 NT) — the production geometry, no bounds anywhere; !FULL: a shorter trace (L % 4 == 0)
+// FULL: the trace fills the tile (L = 16 NT) — the production geometry, no bounds anywhere; !FULL: a shorter trace (any length)
 template <int NT, int M, bool SEP, bool FULL>
 __global__ void __launch_bounds__(NT, SEP ? 4 : (NT == 64 ? 5 : (FULL ? LDSP_L3_WPS : LDSP_L3_RWPS)))   // (one-wave workgroups: 96 registers)
 icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOutDev out, const float* __restrict__ ext_bl,
@@ -406,7 +406,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
 #else
   constexpr bool STUDY = false;
 #endif
-  // Trace length: the tile (Lp = 16 NT samples) or less (L % 4 == 0, the host admits nothing else).  A lane whose quad of row 2 or 3
+  // Trace length: the tile (Lp = 16 NT samples) or less (more than half of it).  A lane whose quad of row 2 or 3
   // lies beyond L keeps a COPY OF ITS OWN ROW-0 QUAD there (rows 0 and 1 always lie inside the trace: the tile is the smallest that
   // holds it): real sample values, so the raw extremes are unchanged, and no load address is clamped; every filter of the chain is
   // causal up to its own output range, every output range is bounded by L below (nout, ng, the crossing tests), and the one
@@ -432,18 +432,24 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   const uint16_t* w16 = reinterpret_cast<const uint16_t*>(wf) + (size_t)blockIdx.x * (size_t)L;
   auto wv = [&](int i) { return (!STUDY && P.in_u16) ? (float)w16[i] : w[i]; };
   // (!FULL: the tile is the smallest that holds the trace, so rows 0 and 1 lie inside it; a lane whose quad of row 2 or 3 lies beyond
-  // the trace keeps a copy of its own row-0 quad there — real sample values: the raw extremes do not change)
+  // the trace keeps a copy of its own row-0 quad there — real sample values: the raw extremes do not change.  L % 4 != 0: the one
+  // quad that holds the end of the trace is read sample by sample — nothing behind the trace is touched — and keeps the row-0
+  // copy in its last elements; the rows are then only 4-byte aligned, which global_load_dwordx4 / dwordx2 accept)
+  auto load_last_quad = [&](f4 q, int i0) {   // 1..3 samples of the trace from i0 on (one thread of the workgroup), the others as given
+    const float a = wv(i0), b = (i0 + 1 < L) ? wv(i0 + 1) : q.y, c = (i0 + 2 < L) ? wv(i0 + 2) : q.z;
+    return (f4){a, b, c, q.w};
+  };
   if ((!STUDY && P.in_u16)) {   // (block-uniform)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (!FULL && r >= 2) { x[r] = x[0]; if (4 * (tid + NT * r) >= L) continue; }
+      if (!FULL && r >= 2) { x[r] = x[0]; if (4 * (tid + NT * r) >= L) continue; if (4 * (tid + NT * r) + 4 > L) { x[r] = load_last_quad(x[r], 4 * (tid + NT * r)); continue; } }
       const uint2 q = *reinterpret_cast<const uint2*>(w16 + 4 * (tid + NT * r));
       x[r] = (f4){(float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16)};
     }
   } else {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (!FULL && r >= 2) { x[r] = x[0]; if (4 * (tid + NT * r) >= L) continue; }
+      if (!FULL && r >= 2) { x[r] = x[0]; if (4 * (tid + NT * r) >= L) continue; if (4 * (tid + NT * r) + 4 > L) { x[r] = load_last_quad(x[r], 4 * (tid + NT * r)); continue; } }
       x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
     }
   }
@@ -597,7 +603,10 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         } else {
           v = *reinterpret_cast<const f4*>(w + in_trace(i0));
         }
-        if (!FULL && i0 >= L) v = (f4){NAN, NAN, NAN, NAN};   // beyond the trace: equal to neither rail
+        if (!FULL && i0 + 4 > L) {   // beyond the trace: equal to neither rail (the quad that holds the end: sample by sample)
+          v = (f4){NAN, NAN, NAN, NAN};
+          if (i0 < L) v = load_last_quad(v, i0);
+        }
         n_low += (v.x == lo_) + (v.y == lo_) + (v.z == lo_) + (v.w == lo_);
         n_high += (v.x == hi_) + (v.y == hi_) + (v.z == hi_) + (v.w == hi_);
         *reinterpret_cast<f4*>(&S.X[4 * (tid + NT * r)]) = v;
@@ -1673,7 +1682,9 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       d[r][1].y = fmaf(Z.eps, y[r].z, (y[r].w - y[r].z) + mec);
       if (r == 0 && tid == 0) d[0][0].x = 0.f;
       if (!FULL && 4 * NT * (r + 1) > L) {   // (block-uniform) a row that reaches beyond the trace: d = 0 there
-        if (4 * (opaque(tid) + NT * r) >= L) { d[r][0] = splat(0.f); d[r][1] = splat(0.f); }
+        const int nv = L - 4 * (opaque(tid) + NT * r);   // samples of the trace in this quad
+        if (nv <= 0) { d[r][0] = splat(0.f); d[r][1] = splat(0.f); }
+        else if (nv < 4) { if (nv < 2) d[r][0].y = 0.f; if (nv < 3) d[r][1].x = 0.f; d[r][1].y = 0.f; }
       }
     }
     STAMP(19); DSTOP(19);
@@ -1867,7 +1878,7 @@ size_t icpc_lean3_smem_bytes(int NT, int Lf) {
 }
 
 // sg_slots: 7 or 13 (the smallest that holds the three Savitzky-Golay windows)
-// full: the traces fill the tile (L = 16 NT); otherwise shorter traces (L % 4 == 0, more than half the tile)
+// full: the traces fill the tile (L = 16 NT); otherwise shorter traces (more than half the tile)
 hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, bool full, const IcpcDev* dP, const IcpcOutDev& out,
                              const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st) {
 #ifdef LDSP_DEV_512

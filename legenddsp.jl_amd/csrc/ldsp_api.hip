@@ -450,13 +450,14 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, int r2, Ic
 // eps * T term of the filters' last tap, which icpc_lean3 drops, is far below the columns' resolution: |w_last| * eps * rail * L
 // < 1e-2 on a trace that sits at the rail, a hundredth of that on a real one (dsp_icpc sets the filters' tau to 1e7 us,
 // src/dsp_icpc.jl:98: 1.4e-3 for a 16-bit rail and 8192 samples).  ldsp_icpc_run and ldsp_icpc_pz_trap_run decide alike.
-// `full_tile`: only traces that fill the tile (config 2's lean kernel); the fused kernel also takes shorter traces whose length is a
-// multiple of four samples (16-byte rows: quads are loaded whole) — 8000-, 7300-, 6000-sample traces run it on the next tile up.
+// `full_tile`: only traces that fill the tile (config 2's lean kernel); the fused kernel also takes shorter traces of any length
+// (8000-, 7300-, 8190-, 7001-sample traces run it on the next tile up; when the length is no multiple of four samples the rows are
+// 4-byte aligned and the quad that holds the end of a trace is read sample by sample).
 static bool icpc_lean_applies(const ldsp_ctx* c, bool full_tile = false) {
   const IcpcDev& H = c->icpc_host;
   const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
   if (c->icpc_generic || c->two_kernel || !(c->dbg_stop == 0 || c->dbg_stop >= 100) || H.R != 4 || H.L > 16 * H.NT || H.NT > 512 ||
-      (H.L & 3) != 0 || H.L <= 8 * H.NT || (full_tile && H.L != 16 * H.NT) ||   // (more than half the tile: its first two rows are in the trace)
+      H.L <= 8 * H.NT || (full_tile && H.L != 16 * H.NT) ||   // (more than half the tile: its first two rows are in the trace)
       H.cusp_mode != 1 || !H.t0inv_same || H.tx_mintot > 2 || sg_max > 13)
     return false;
   const double rail = std::max(std::fabs((double)H.sat_high), std::fabs((double)H.sat_low)) * (double)H.L;

@@ -274,12 +274,15 @@ def test_threshold_crossings_with_spikes_before_the_pulse(orc, params):
 
 @pytest.mark.parametrize("length,kernel,sep", [(8000, "lean3::icpc_lean3_kernel", False), (7300, "lean3::icpc_lean3_kernel", False),
                                                 (4400, "lean3::icpc_lean3_kernel", False), (7600, "lean3::icpc_lean3_kernel", True),
-                                                (8190, "icpc_kernel", False), (7301, "icpc_kernel", False)])
+                                                (8190, "lean3::icpc_lean3_kernel", False), (7301, "lean3::icpc_lean3_kernel", False),
+                                                (4403, "lean3::icpc_lean3_kernel", False), (7602, "lean3::icpc_lean3_kernel", True),
+                                                (4096 + 1, "lean3::icpc_lean3_kernel", False), (8191, "lean3::icpc_lean3_kernel", True)])
 def test_traces_shorter_than_the_tile(orc, length, kernel, sep):
-    """A trace that does not fill the tile (16 x threads samples) still runs the fused lean kernel when its rows are 16-byte
-    aligned (length % 4 == 0: quads are loaded whole; a lane whose quad lies beyond the trace keeps a copy of its own row-0 quad
-    and every output range is bounded by the length) — 8000-, 7300-, 4400-sample traces; other lengths run icpc_kernel.  Both against the oracle on
-    traces whose pulse, tail and windows reach to the very end of the trace, and the lean kernel against the generic one."""
+    """A trace that does not fill the tile (16 x threads samples) still runs the fused lean kernel (a lane whose quad lies beyond
+    the trace keeps a copy of its own row-0 quad and every output range is bounded by the length) — also when its length is no
+    multiple of four samples (round 4: the rows are then 4-byte aligned and the one quad that holds the end of a trace is read
+    sample by sample): lengths % 4 = 0, 1, 2, 3, one sample more than half the tile, one less than the tile.  Against the oracle on
+    traces whose pulse, tail and windows reach to the very end of the trace, and against the generic kernel."""
     sc = length / 8192.0
     dt = 16.0
     us = ldsp.us
@@ -316,8 +319,9 @@ def test_traces_shorter_than_the_tile(orc, length, kernel, sep):
 
 def test_context_changes_stream_and_can_leave_a_destroyed_one(params):
     """ldsp_ctx_set_stream (include/ldsp.h, lifetime rule): run on stream A, switch to B (ordered behind A by an event), destroy A's
-    successor while the context still points at it, and switch again — the context must adopt the new stream (device
-    synchronisation in place of the event) instead of failing on the dead one for ever; the tables are the same every time."""
+    successor while the context still points at it, and switch again — the context must adopt the new stream (it waits for the
+    event recorded at the end of its last run and never touches the old stream) instead of failing on the dead one for ever; the
+    tables are the same every time."""
     wf = ldsp.synth.hpge_batch(64, L, device="cuda", seed=5)
     torch.cuda.synchronize()                         # (the batch is complete before another stream reads it)
     ctx = ldsp.Context(0, use_torch_stream=False)   # (the context launches where set_stream says, not on torch's current stream)
@@ -371,7 +375,8 @@ def _scaled_config(length, dt, degree2):
 @pytest.mark.parametrize("length,dt,u16,sep", [(2048, 16.0, False, False), (1024, 32.0, False, False),      # full tiles of 128 / 64 threads
                                                  (4096, 32.0, False, True),                                   # 256 threads, CUSP and ZAC separate
                                                  (3000, 16.0, False, False), (1500, 16.0, True, False),       # short tiles of 256 / 128 threads (uint16 input)
-                                                 (900, 32.0, False, True), (1800, 16.0, True, True)])         # short tiles of 64 / 128 threads, separate CUSP / ZAC
+                                                 (900, 32.0, False, True), (1800, 16.0, True, True),          # short tiles of 64 / 128 threads, separate CUSP / ZAC
+                                                 (3001, 16.0, True, False), (1503, 16.0, False, False), (1798, 16.0, True, True)])   # lengths that are no multiple of four samples (uint16 rows 2-byte aligned)
 def test_small_tiles_run_the_lean_kernel(orc, length, dt, u16, sep):
     """Every instantiation the launcher admits (ldsp_api.hip: icpc_lean_applies) is compared with the oracle by name: tiles of 64, 128
     and 256 threads (L = 1024, 2048, 4096), full and shorter than the tile, float32 and uint16 input, shared and separately optimised

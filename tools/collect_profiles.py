@@ -3,7 +3,7 @@ secondary results), rocprofv3 kernel statistics of the bench command and of the 
 built from the FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE x2 on gfx950 for 16 B/lane streaming loads, MI355X_MICROARCH.md HBM
 section) — one record per workload of the bench command (bench.py looks them up by kernel name, batch size and trace length).
 Usage: python tools/collect_profiles.py r02a"""
-import csv, json, os, shutil, sys, collections
+import csv, json, os, re, shutil, sys, collections
 tag = sys.argv[1]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(R, "gpurun_out", tag), os.path.join(R, "profiles")
@@ -19,14 +19,14 @@ if os.path.exists(kt):
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(kt)):
         if r["Kernel_Name"].startswith("void ldsp::"):
-            per[r["Kernel_Name"].replace("void ", "").split("(")[0]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+            per[(r["Kernel_Name"].replace("void ", "").split("(")[0], int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]))].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     with open(os.path.join(dst, f"{tag}_bench_kernel_stats_warm.csv"), "w") as g:
-        g.write("kernel,launches,first_launch_ns,warm_launches,warm_avg_ns,warm_min_ns,warm_max_ns\n")
-        for k, v in sorted(per.items()):
+        g.write("kernel,traces,launches,first_launch_ns,warm_launches,warm_avg_ns,warm_min_ns,warm_max_ns\n")
+        for (k, nd), v in sorted(per.items()):
             v.sort()
             d = [x[1] for x in v]
             w = d[1:] if len(d) > 1 else d
-            g.write(f'"{k}",{len(d)},{d[0]},{len(w)},{sum(w) / len(w):.0f},{min(w)},{max(w)}\n')
+            g.write(f'"{k}",{nd},{len(d)},{d[0]},{len(w)},{sum(w) / len(w):.0f},{min(w)},{max(w)}\n')
 for t in ("gpu_time_grid", "gpu_time_compressed", "gpu_time_multi_intersect"):
     ks = os.path.join(src, f"stats_{t}", "p_kernel_stats.csv")
     if os.path.exists(ks):
@@ -34,26 +34,36 @@ for t in ("gpu_time_grid", "gpu_time_compressed", "gpu_time_multi_intersect"):
     lg = os.path.join(src, f"{t}.log")
     if os.path.exists(lg):
         with open(lg) as f, open(os.path.join(dst, f"{tag}_{t[9:]}_timing.txt"), "w") as g:
-            g.write("".join(l for l in f if "amdgpu.ids" not in l and not l.startswith("[rocprofv3]") and "rocprofiler" not in l))
-# workloads of the bench command: which (n_traces, L) a kernel of the PMC passes ran on.  icpc_lean3_kernel<NT, M, SEP, FULL>: the
-# headline is <.., false, true>; the secondary dsp_icpc lines run <.., true, true> (CUSP / ZAC optimised separately), <.., false, false>
-# (a trace shorter than the tile) and the generic icpc_kernel (a length the lean kernel does not take)
-shapes = {"headline": (bench["config"]["traces_per_gpu"], bench["config"]["samples"])}
+            g.write("".join(l for l in f if "amdgpu.ids" not in l and not l.startswith("[rocprofv3]") and "rocprofiler" not in l
+                            and not re.match(r"[WEI]\d{8} ", l)))   # (glog lines of the profiler itself)
+# workloads of the bench command: which (n_traces, L) a kernel of the PMC passes ran on.  A dispatch is identified by its kernel name
+# AND its number of workgroups (= traces): icpc_lean3_kernel<NT, M, SEP, FULL> is the headline <.., false, true>, and the secondary
+# dsp_icpc lines run <.., true, true> (CUSP / ZAC optimised separately), <.., false, false> twice (a trace shorter than the tile; a length
+# that is no multiple of four samples — told apart by their batch sizes) and the generic icpc_kernel (a parameter set the lean kernel
+# does not take)
+lines = [("headline", bench["config"]["traces_per_gpu"], bench["config"]["samples"])]
 for sec in bench.get("secondary", []):
-    shp = (sec["config"]["traces_per_gpu"], sec["config"]["samples"])
-    if "pole-zero" in sec["metric"]: shapes["pz_trap"] = shp
-    elif "dsp_sipm" in sec["metric"]: shapes["k_sipm"] = shp
-    elif "separately" in sec["config"]["workload"]: shapes["sep"] = shp
-    elif "fallback" in sec["config"]["workload"]: shapes["icpc_kernel<"] = shp
-    elif "shorter than the tile" in sec["config"]["workload"]: shapes["short"] = shp
+    n_, L_ = sec["config"]["traces_per_gpu"], sec["config"]["samples"]
+    wl = sec["config"]["workload"]
+    if "pole-zero" in sec["metric"]: lines.append(("pz_trap", n_, L_))
+    elif "dsp_sipm" in sec["metric"]: lines.append(("k_sipm", n_, L_))
+    elif "separately" in wl: lines.append(("sep", n_, L_))
+    elif "fallback" in wl: lines.append(("icpc_kernel<", n_, L_))
+    else: lines.append(("short", n_, L_))
 
 
-def shape_of(k):
-    if "icpc_lean3_kernel<" in k:
-        targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
-        sep, full = targs[2] == "true", (len(targs) < 4 or targs[3] == "true")
-        return shapes.get("sep") if sep else shapes.get("headline") if full else shapes.get("short")
-    return next((sh for frag, sh in shapes.items() if frag in k and frag not in ("headline", "sep", "short")), None)
+def shape_of(k, n):
+    for kind, n_, L_ in lines:
+        if n_ != n:
+            continue
+        if "icpc_lean3_kernel<" in k:
+            targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+            sep, full = targs[2] == "true", (len(targs) < 4 or targs[3] == "true")
+            if kind == ("sep" if sep else "headline" if full else "short"):
+                return (n_, L_)
+        elif kind not in ("headline", "sep", "short") and kind in k:
+            return (n_, L_)
+    return None
 
 
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -62,12 +72,13 @@ for ctr, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     names = {}
     for r in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv"))):
         if r["Counter_Name"] == ctr and r["Kernel_Name"].startswith("void ldsp::"):
-            per_dispatch[r["Dispatch_Id"]] += float(r["Counter_Value"]); names[r["Dispatch_Id"]] = r["Kernel_Name"]
+            per_dispatch[r["Dispatch_Id"]] += float(r["Counter_Value"])
+            names[r["Dispatch_Id"]] = (r["Kernel_Name"].replace("void ", "").split("(")[0], int(r["Grid_Size"]) // int(r["Workgroup_Size"]))
     for k, v in per_dispatch.items():
-        acc[names[k].replace("void ", "").split("(")[0]][ctr].append(v)
+        acc[names[k]][ctr].append(v)
 recs = []
-for k, v in acc.items():
-    shape = shape_of(k)
+for (k, n_disp), v in acc.items():
+    shape = shape_of(k, n_disp)
     if shape is None or not v["FETCH_SIZE"] or not v["WRITE_SIZE"]:
         continue
     fa, wa = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]), sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
