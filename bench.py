@@ -514,7 +514,7 @@ def run_rank(args):
                 sec.append(bench_sipm(env, args, 625_000, 16384))         # BASELINE config 5's single-GPU shard
                 # parameter sets beside the headline's: a trace shorter than the tile -> the bounded instantiation; a length that is no
                 # multiple of four samples -> the same instantiation since round 4 (4-byte aligned rows; its batch size differs from the
-                # line before so that the profiles can tell the two apart); an optimised Savitzky-Golay window of 19 taps -> icpc_kernel
+                # line before so that the profiles can tell the two apart); a Savitzky-Golay window of 27 taps -> icpc_kernel
                 # (the generic kernel: what leaving the lean kernel costs); CUSP and ZAC optimised separately -> the two-pass instantiation
                 import legenddsp_jl_amd as ldsp
                 us = ldsp.us
@@ -522,8 +522,8 @@ def run_rank(args):
                 sec.append(r_short)
                 r_odd, _ = bench_icpc(env, args, 196_608, 8190, "icpc", label="196608 x 8190 f32: a length that is no multiple of four samples (4-byte aligned rows) -> the bounded instantiation of the same kernel (the generic kernel until round 3)")
                 sec.append(r_odd)
-                r_gen, _ = bench_icpc(env, args, 262_144, 8192, "icpc", pars_filter={"sg": {"wl": 300.0 * ldsp.ns}},
-                                      label="fallback: 262144 x 8192 f32 with an optimised Savitzky-Golay window of 300 ns (19 taps > the 13 the lean kernel unrolls) -> generic icpc_kernel")
+                r_gen, _ = bench_icpc(env, args, 262_144, 8192, "icpc", pars_filter={"sg": {"wl": 430.0 * ldsp.ns}},
+                                      label="fallback: 262144 x 8192 f32 with a Savitzky-Golay window of 430 ns (27 taps; the lean kernel takes 25 = the end of the reference's scan grid) -> generic icpc_kernel")
                 sec.append(r_gen)
                 r_sep, _ = bench_icpc(env, args, 262_144, 8192, "icpc", pars_filter={"cusp": {"rt": 4.0 * us, "ft": 1.5 * us}, "zac": {"rt": 5.5 * us, "ft": 2.0 * us}},
                                       label="262144 x 8192 f32, CUSP and ZAC optimised separately (pars_filter): two passes of the closed-form stage in one launch")

@@ -174,11 +174,12 @@ __host__ __device__ inline int cz_pad_floats(int Lf) { return (Lf + 2 + 7) & ~3;
 // LDS: [gap: mask words / Dp[i < 0] = 0][X: Lp + 64][8-byte data][4-byte data][slack]: a lane-strided read X[k + shift] of the row
 // pair that holds the end of an output range runs at most 2 NT floats past X (masked by the caller): those addresses stay
 // inside the allocation.
+constexpr int NH_MAX = 6;   // halo quads of the widest Savitzky-Golay window the kernel takes (25 taps: 4 + 24 samples)
 template <int NT>
 struct Smem {
   static constexpr int NW = NT / 64, Lp = NT * SP, NWORDS = Lp / 32;
   static constexpr int NSMALL = 2 * R * NW /*part*/ + 3 * R * NW /*scn*/ + 5 * NW /*wred*/ + NWSUM * NW /*wsum*/ + C_NCOLS + 32 /*outv, misc*/ +
-                                2 * EST_TBL + (4 * 3 + 1) * (R * NW + 1) /*hy: up to 3 halo quads + the last sample per wave-row*/;
+                                2 * EST_TBL + (4 * NH_MAX + 1) * (R * NW + 1) /*hy: up to NH_MAX halo quads + the last sample per wave-row*/;
   uint32_t* bm;    // [NMASKROWS][NWORDS] in the gap in front of X
   float* X;        // [Lp + 64]
   double* dpart;   // [2][R*NW]  double prefix sum of the ZAC parabolas
@@ -208,7 +209,7 @@ struct Smem {
     scn = part + 2 * R * NW;
     estB = scn + 3 * R * NW;
     hy = estB + 2 * EST_TBL;
-    float* wred_ = hy + (4 * 3 + 1) * (R * NW + 1);
+    float* wred_ = hy + (4 * NH_MAX + 1) * (R * NW + 1);
     lds_float* base = (lds_float*)wred_;
     asm volatile("" : "+v"(base));   // one VGPR base for the small arrays (they lie beyond the reach of a zero-based immediate)
     wred = base;
@@ -757,7 +758,12 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     }
   }
   // the first NH quads of every wave-row: halo of the previous wave-row's last lanes (sweep A's short leg, Savitzky-Golay)
+  // (M <= 13: the whole window of a quad's four outputs — M + 3 samples — waits in registers; M = 25, optimised Savitzky-Golay windows
+  // of up to 350 ns at 16 ns: the main filter streams through the halo quads, two at a time, and only the two fixed short filters
+  // — at most MS = 13 taps, the host admits nothing else — use a register window)
   constexpr int NH = (M + 3 - 4 + 3) / 4;
+  static_assert(NH <= NH_MAX, "halo table");
+  constexpr int MS = M <= 13 ? M : 13, NHS = (MS + 3 - 4 + 3) / 4;
   float* hyl = S.hy + 4 * NH * (R * NW + 1);
   if (lane < NH) {
 #pragma unroll
@@ -980,11 +986,11 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   // masks of the main filter's output need thresholds that follow from them: the outputs wait in X — each thread's own quads, which
   // nobody else reads — instead of in sixteen registers across the exchange.
   const int ng = L - P.sg_npts[0] + 1;
-  auto sg_window = [&](int r, float (&wv_)[4 + 4 * NH]) {
+  auto sg_window = [&](int r, float (&wv_)[4 + 4 * NHS]) {
     wv_[0] = y[r].x; wv_[1] = y[r].y; wv_[2] = y[r].z; wv_[3] = y[r].w;
     f4 h = y[r];
 #pragma unroll
-    for (int j = 0; j < NH; ++j) {
+    for (int j = 0; j < NHS; ++j) {
       h = halo_next(h, r, j);
       wv_[4 + 4 * j] = h.x; wv_[5 + 4 * j] = h.y; wv_[6 + 4 * j] = h.z; wv_[7 + 4 * j] = h.w;
     }
@@ -995,15 +1001,34 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     sgc0[i] = P.sg_c[0][i];   // zero beyond the filter's own taps (the host zero-fills the block)
     if (LDSP_L3_SGC_VGPR) asm volatile("" : "+v"(sgc0[i]));
   }
-  auto sg_main = [&](int r, const float (&wv_)[4 + 4 * NH], float (&go)[4]) {   // -inf beyond the output axis
+  auto sg_main = [&](int r, const float (&wv_)[4 + 4 * NHS], float (&go)[4]) {   // -inf beyond the output axis
     const int i0 = 4 * (opaque(tid) + NT * r);
 #pragma unroll
     for (int e = 0; e < 4; ++e) go[e] = 0.f;
+    if constexpr (M <= 13) {
 #pragma unroll
-    for (int i = 0; i < M; ++i) {
-      const float c = sgc0[i];
+      for (int i = 0; i < M; ++i) {
+        const float c = sgc0[i];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) go[e] = fmaf(c, wv_[e + i], go[e]);
+        for (int e = 0; e < 4; ++e) go[e] = fmaf(c, wv_[e + i], go[e]);
+      }
+    } else {   // taps 4j .. 4j+3 read the samples 4j .. 4j+6 of the window: the quads j and j + 1
+      f4 h0 = y[r];
+#pragma unroll
+      for (int j = 0; j < (M + 3) / 4; ++j) {
+        const int last = (4 * j + 3 < M - 1) ? 4 * j + 3 : M - 1;   // the chunk's last tap
+        f4 h1 = h0;
+        if (last + 3 >= 4 * j + 4) h1 = halo_next(h0, r, j);
+        const float win[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (4 * j + t >= M) continue;
+          const float c = sgc0[4 * j + t];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) go[e] = fmaf(c, win[e + t], go[e]);
+        }
+        h0 = h1;
+      }
     }
     if (wrow(r) + 255 >= ng) {   // only the wave-row holding the end of the output axis
 #pragma unroll
@@ -1029,8 +1054,8 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i0 = 4 * (opaque(tid) + NT * r);
-      float wv_[4 + 4 * NH], go[4];
-      sg_window(r, wv_);
+      float wv_[4 + 4 * NHS], go[4];
+      if constexpr (M <= 13) sg_window(r, wv_);
       sg_main(r, wv_, go);
       gmax = vmax3(vmax3(gmax, go[0], go[1]), go[2], go[3]);
       *reinterpret_cast<f4*>(&S.X[i0]) = (f4){go[0], go[1], go[2], go[3]};
@@ -1055,6 +1080,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       }
       if (!row_out(cls_curx, r)) {   // SG(60 ns), SG(100 ns), plain derivative: only rows that touch the current window
         // (one filter at a time, its four outputs tracked before the next one's are computed)
+        if constexpr (M > 13) sg_window(r, wv_);
         auto others = [&](auto in_tag) {
         constexpr bool IN = decltype(in_tag)::value;
 #pragma unroll
@@ -1062,7 +1088,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
           if (f == 2 && (STUDY || P.sg_same_02)) continue;
           float gf[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int i = 0; i < M; ++i) {
+          for (int i = 0; i < MS; ++i) {
             const float c = P.sg_c[f][i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) gf[e] = fmaf(c, wv_[e + i], gf[e]);
@@ -1148,13 +1174,18 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   // filter f at output index k from y in LDS (the few samples the parabolas and crossing interpolations need)
   auto flt_at = [&](int f, int k) -> float {
     if (f < 3) {
-      float a[M];
-#pragma unroll
-      for (int i = 0; i < M; ++i) a[i] = S.X[k + i];
-      asm volatile("" ::: "memory");
       float gq = 0.f;
+      constexpr int CH = M <= 13 ? M : 9;   // samples read together (one wait)
 #pragma unroll
-      for (int i = 0; i < M; ++i) gq = fmaf(P.sg_c[f][i], (i < P.sg_npts[f]) ? a[i] : 0.f, gq);
+      for (int c0 = 0; c0 < M; c0 += CH) {
+        float a[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) a[i] = (c0 + i < M) ? S.X[k + c0 + i] : 0.f;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          if (c0 + i < M) gq = fmaf(P.sg_c[f][c0 + i], (c0 + i < P.sg_npts[f]) ? a[i] : 0.f, gq);
+      }
       return gq;
     }
     return S.X[max(k, 1)] - S.X[max(k - 1, 0)];
@@ -1417,7 +1448,10 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         if (lane == 0) { S.misc[10] = __int_as_float(i0z); S.misc[11] = uz; S.misc[13] = S.X[i0z]; }
       }
     }
-    if (wave == 1 % NW || wave == 2 % NW) {
+    // (two-wave tiles: wave 1 alone, both passes — `2 % NW` named wave 0 as well, which has no t0 position (the block above computes it in
+    // waves 1 % NW and NW - 1 only), and the two waves raced for the result slots: qdrift = NaN in some launches of the 128-thread tile,
+    // found by the second-launch comparison of tests/test_icpc_gpu.py::test_small_tiles_run_the_lean_kernel in round 4)
+    if ((NW > 2) ? (wave == 1 || wave == 2) : (wave == 1 % NW)) {
       const bool lq = (NW > 2) ? wave == 2 : false;
       for (int pass = 0; pass < ((NW > 2) ? 1 : 2); ++pass) {
         const bool is_lq = (NW > 2) ? lq : pass == 1;
@@ -1877,7 +1911,7 @@ size_t icpc_lean3_smem_bytes(int NT, int Lf) {
   }
 }
 
-// sg_slots: 7 or 13 (the smallest that holds the three Savitzky-Golay windows)
+// sg_slots: 7, 13 or 25 (the smallest that holds the main Savitzky-Golay window; the two fixed ones have at most 13 taps)
 // full: the traces fill the tile (L = 16 NT); otherwise shorter traces (more than half the tile)
 hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, bool full, const IcpcDev* dP, const IcpcOutDev& out,
                              const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st) {
@@ -1889,10 +1923,10 @@ hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, b
 #define LDSP_ARGS wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st
 #define LDSP_CASE(N) \
   case N: \
-    if (!full) return cz_shared ? (sg_slots <= 7 ? lean3::launch_t<N, 7, false, false>(LDSP_ARGS) : lean3::launch_t<N, 13, false, false>(LDSP_ARGS)) \
-                                : (sg_slots <= 7 ? lean3::launch_t<N, 7, true, false>(LDSP_ARGS) : lean3::launch_t<N, 13, true, false>(LDSP_ARGS)); \
-    return cz_shared ? (sg_slots <= 7 ? lean3::launch_t<N, 7, false, true>(LDSP_ARGS) : lean3::launch_t<N, 13, false, true>(LDSP_ARGS)) \
-                     : (sg_slots <= 7 ? lean3::launch_t<N, 7, true, true>(LDSP_ARGS) : lean3::launch_t<N, 13, true, true>(LDSP_ARGS));
+    if (!full) return cz_shared ? (sg_slots <= 7 ? lean3::launch_t<N, 7, false, false>(LDSP_ARGS) : sg_slots <= 13 ? lean3::launch_t<N, 13, false, false>(LDSP_ARGS) : lean3::launch_t<N, 25, false, false>(LDSP_ARGS)) \
+                                : (sg_slots <= 7 ? lean3::launch_t<N, 7, true, false>(LDSP_ARGS) : sg_slots <= 13 ? lean3::launch_t<N, 13, true, false>(LDSP_ARGS) : lean3::launch_t<N, 25, true, false>(LDSP_ARGS)); \
+    return cz_shared ? (sg_slots <= 7 ? lean3::launch_t<N, 7, false, true>(LDSP_ARGS) : sg_slots <= 13 ? lean3::launch_t<N, 13, false, true>(LDSP_ARGS) : lean3::launch_t<N, 25, false, true>(LDSP_ARGS)) \
+                     : (sg_slots <= 7 ? lean3::launch_t<N, 7, true, true>(LDSP_ARGS) : sg_slots <= 13 ? lean3::launch_t<N, 13, true, true>(LDSP_ARGS) : lean3::launch_t<N, 25, true, true>(LDSP_ARGS));
   switch (NT) {
     LDSP_LEAN_CASES
     default: return hipErrorInvalidValue;

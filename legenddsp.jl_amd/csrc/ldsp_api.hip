@@ -446,7 +446,7 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, int r2, Ic
 // The lean kernels (icpc_lean3.hip: the fused chain; icpc_lean.hip: config 2's sub-chain) cover the standard geometry: the trace
 // fills the tile (L = 16 NT, NT <= 512), CUSP and ZAC in closed form (sharing their geometry: one pass; optimised separately:
 // one pass each inside the same launch), the inverted t0 uses the same trapezoid, tx_mintot <= 2 samples, Savitzky-Golay windows
-// of at most 13 taps, the chain of ZAC shifts with the parabola's last tap folded in exists (icpc_dev.hpp: zf_*), and the
+// of at most 25 taps (the optimised one) / 13 taps (the two fixed ones), the chain of ZAC shifts with the parabola's last tap folded in exists (icpc_dev.hpp: zf_*), and the
 // eps * T term of the filters' last tap, which icpc_lean3 drops, is far below the columns' resolution: |w_last| * eps * rail * L
 // < 1e-2 on a trace that sits at the rail, a hundredth of that on a real one (dsp_icpc sets the filters' tau to 1e7 us,
 // src/dsp_icpc.jl:98: 1.4e-3 for a 16-bit rail and 8192 samples).  ldsp_icpc_run and ldsp_icpc_pz_trap_run decide alike.
@@ -455,10 +455,12 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, int r2, Ic
 // 4-byte aligned and the quad that holds the end of a trace is read sample by sample).
 static bool icpc_lean_applies(const ldsp_ctx* c, bool full_tile = false) {
   const IcpcDev& H = c->icpc_host;
-  const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
+  // (Savitzky-Golay: the optimised window up to 25 taps — 350 ns at 16 ns, the end of the reference's scan grid, test/test_dsp_icpc.jl:134-138 —,
+  // the two fixed windows, 60 and 100 ns, up to 13; a third filter equal to the first is not evaluated again)
+  const int sg_fixed = std::max(H.sg_npts[1], H.sg_same_02 ? 0 : H.sg_npts[2]);
   if (c->icpc_generic || c->two_kernel || !(c->dbg_stop == 0 || c->dbg_stop >= 100) || H.R != 4 || H.L > 16 * H.NT || H.NT > 512 ||
       H.L <= 8 * H.NT || (full_tile && H.L != 16 * H.NT) ||   // (more than half the tile: its first two rows are in the trace)
-      H.cusp_mode != 1 || !H.t0inv_same || H.tx_mintot > 2 || sg_max > 13)
+      H.cusp_mode != 1 || !H.t0inv_same || H.tx_mintot > 2 || H.sg_npts[0] > 25 || sg_fixed > 13)
     return false;
   const double rail = std::max(std::fabs((double)H.sat_high), std::fabs((double)H.sat_low)) * (double)H.L;
   const double drop = std::max(std::fabs((double)H.cusp.w_last) * H.cusp.eps, std::fabs((double)H.zac.w_last) * H.zac.eps) * rail;

@@ -435,6 +435,38 @@ def test_separately_optimised_cusp_and_zac_run_in_the_lean_launch(orc):
         assert worst <= parity.FLIP_FRAC, "\n".join(lines)
 
 
+@pytest.mark.parametrize("wl_ns,taps,length,sep,kernel", [(240.0, 15, 8192, False, "lean3::icpc_lean3_kernel"), (300.0, 19, 8192, True, "lean3::icpc_lean3_kernel"),
+                                                          (350.0, 23, 8000, False, "lean3::icpc_lean3_kernel"), (400.0, 25, 8190, False, "lean3::icpc_lean3_kernel"),
+                                                          (430.0, 27, 8192, False, "icpc_kernel")])
+def test_optimised_savitzky_golay_windows_run_the_lean_kernel(orc, wl_ns, taps, length, sep, kernel):
+    """pars_filter.sg.wl from the reference's scan grid (30 ... 350 ns, test/test_dsp_icpc.jl:134-138; 22 samples -> 23 taps at 16 ns):
+    windows of up to 25 taps run the fused lean kernel since round 4 (the main filter streams through the halo quads instead of keeping
+    its window in registers; until round 3 more than 13 taps meant the generic kernel at half the rate), full and short tiles, shared
+    and separate CUSP / ZAC; 27 taps still run icpc_kernel.  Against the oracle, and the lean kernel against the generic one."""
+    us = ldsp.us
+    pf = {"sg": {"wl": wl_ns * ldsp.ns}}
+    if sep:
+        pf.update({"cusp": {"rt": 4.0 * us, "ft": 1.5 * us}, "zac": {"rt": 5.5 * us, "ft": 2.0 * us}})
+    p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * us, pf, length, 0.0, 16.0)
+    assert p.sg_npts[0] == taps
+    n = 128
+    wf = ldsp.synth.hpge_batch(n, 8192, device="cuda", seed=83)[:, :length].contiguous()
+    host = wf.cpu().numpy()
+    ora = orc.dsp_icpc(host, p, nthreads=16)
+    ctx = ldsp.default_context()
+    gpu = _run(wf, p)
+    assert ctx.last_kernel_name() == kernel
+    lines, worst = parity.compare(gpu, ora, wf=host, params=p, orc=orc)
+    assert worst <= 2 / n, "\n".join(l for l in lines if f"bad=0/{n}" not in l)
+    if kernel.startswith("lean3"):
+        gen = _run(wf, p, generic=1)
+        assert ctx.last_kernel_name() == "icpc_kernel"
+        for c in parity.INT_COLS:
+            assert (np.abs(gpu[c].astype(np.int64) - gen[c].astype(np.int64)) > 0).sum() <= 2, c
+        for c in ("a_sg", "t50_current"):
+            np.testing.assert_allclose(gpu[c], gen[c], rtol=3e-5, atol=1e-3, err_msg=c)
+
+
 @pytest.mark.parametrize("generic,two_kernel", [(0, 0), (1, 0), (0, 1)])
 def test_uint16_adc_counts_are_converted_by_the_kernel(params, generic, two_kernel):
     """ldsp_icpc_opts.in_u16: the traces as uint16 ADC counts (what production waveforms are) give the table of the same
