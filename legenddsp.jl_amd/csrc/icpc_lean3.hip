@@ -394,7 +394,7 @@ __device__ __forceinline__ uint32_t nib_le(f4 v, float t) {
 // SEP: CUSP and ZAC have their own geometry (two passes of the closed-form stage); keeps a second copy of y in registers
 // FULL: the trace fills the tile (L = 16 NT) — the production geometry, no bounds anywhere; !FULL: a shorter trace (any length)
 template <int NT, int M, bool SEP, bool FULL>
-__global__ void __launch_bounds__(NT, SEP ? 4 : (NT == 64 ? 5 : (FULL ? LDSP_L3_WPS : LDSP_L3_RWPS)))   // (one-wave workgroups: 96 registers)
+__global__ void __launch_bounds__(NT, NT == 64 ? 5 : (FULL ? LDSP_L3_WPS : LDSP_L3_RWPS))   // (one-wave workgroups: 96 registers)
 icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOutDev out, const float* __restrict__ ext_bl,
                   float ext_bl_scale) {
   using SM = Smem<NT>;
@@ -436,24 +436,28 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   // the trace keeps a copy of its own row-0 quad there — real sample values: the raw extremes do not change.  L % 4 != 0: the one
   // quad that holds the end of the trace is read sample by sample — nothing behind the trace is touched — and keeps the row-0
   // copy in its last elements; the rows are then only 4-byte aligned, which global_load_dwordx4 / dwordx2 accept)
-  auto load_last_quad = [&](f4 q, int i0) {   // 1..3 samples of the trace from i0 on (one thread of the workgroup), the others as given
+  auto load_last_quad = [&](f4 q, int i0, const float* w, const uint16_t* w16) __attribute__((always_inline)) {   // 1..3 samples of the trace from i0 on (one thread of the workgroup), the others as given
+    auto wv = [&](int i) { return (!STUDY && P.in_u16) ? (float)w16[i] : w[i]; };
     const float a = wv(i0), b = (i0 + 1 < L) ? wv(i0 + 1) : q.y, c = (i0 + 2 < L) ? wv(i0 + 2) : q.z;
     return (f4){a, b, c, q.w};
   };
-  if ((!STUDY && P.in_u16)) {   // (block-uniform)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (!FULL && r >= 2) { x[r] = x[0]; if (4 * (tid + NT * r) >= L) continue; if (4 * (tid + NT * r) + 4 > L) { x[r] = load_last_quad(x[r], 4 * (tid + NT * r)); continue; } }
-      const uint2 q = *reinterpret_cast<const uint2*>(w16 + 4 * (tid + NT * r));
-      x[r] = (f4){(float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16)};
+  auto load_raw = [&](f4 (&x)[R], const float* w, const uint16_t* w16) __attribute__((always_inline)) {   // (the row pointers as arguments: the second call hides them from the compiler, which would otherwise keep the first call's values alive — in scratch — instead of loading again)
+    if ((!STUDY && P.in_u16)) {   // (block-uniform)
+  #pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (!FULL && r >= 2) { x[r] = x[0]; if (4 * (tid + NT * r) >= L) continue; if (4 * (tid + NT * r) + 4 > L) { x[r] = load_last_quad(x[r], 4 * (tid + NT * r), w, w16); continue; } }
+        const uint2 q = *reinterpret_cast<const uint2*>(w16 + 4 * (tid + NT * r));
+        x[r] = (f4){(float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16)};
+      }
+    } else {
+  #pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (!FULL && r >= 2) { x[r] = x[0]; if (4 * (tid + NT * r) >= L) continue; if (4 * (tid + NT * r) + 4 > L) { x[r] = load_last_quad(x[r], 4 * (tid + NT * r), w, w16); continue; } }
+        x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
+      }
     }
-  } else {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (!FULL && r >= 2) { x[r] = x[0]; if (4 * (tid + NT * r) >= L) continue; if (4 * (tid + NT * r) + 4 > L) { x[r] = load_last_quad(x[r], 4 * (tid + NT * r)); continue; } }
-      x[r] = *reinterpret_cast<const f4*>(w + 4 * (tid + NT * r));
-    }
-  }
+  };
+  load_raw(x, w, w16);
   const float pv_bl = wv(P.bl.from);      // pivot of the baseline sums: the window's first sample
   // LSQ basis tables of the two estimators -> LDS: both loads of a thread in flight together, and no loop where the tile has a thread per entry
   if constexpr (NT >= EST_TBL) {
@@ -606,7 +610,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         }
         if (!FULL && i0 + 4 > L) {   // beyond the trace: equal to neither rail (the quad that holds the end: sample by sample)
           v = (f4){NAN, NAN, NAN, NAN};
-          if (i0 < L) v = load_last_quad(v, i0);
+          if (i0 < L) v = load_last_quad(v, i0, w, w16);
         }
         n_low += (v.x == lo_) + (v.y == lo_) + (v.z == lo_) + (v.w == lo_);
         n_high += (v.x == hi_) + (v.y == hi_) + (v.z == hi_) + (v.w == hi_);
@@ -752,7 +756,13 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   if (tid == 0) S.misc[15] = y[0].x;   // y[0] (the CUSP / ZAC stage: Dp = y - y[0] + eps T)
   {   // pivot of signalstats(pole-zero corrected tail): the window's first sample, from its owner's registers
     const int tq = P.tail.from >> 2, tr = tq / NT, te = P.tail.from & 3;   // (block-uniform)
-    if (tid == tq - NT * tr) {
+    // (row by row with a static index: a conditional between the array's own elements is an lvalue — hipcc selects the ADDRESS, and an
+    // array whose address is selected stays in scratch for the whole kernel once it is written a second time, as the SEP form does)
+    if constexpr (SEP) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (r == tr && tid == tq - NT * tr) S.misc[14] = (te == 0) ? y[r].x : (te == 1) ? y[r].y : (te == 2) ? y[r].z : y[r].w;
+    } else if (tid == tq - NT * tr) {   // (the form the single-pass kernel was tuned with: any other costs it three registers to scratch)
       const f4 v = (tr == 0) ? y[0] : (tr == 1) ? y[1] : (tr == 2) ? y[2] : y[3];
       S.misc[14] = (te == 0) ? v.x : (te == 1) ? v.y : (te == 2) ? v.z : v.w;
     }
@@ -1498,11 +1508,38 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   // Dp of d, and a double prefix sum of a sparse combination u of Dp; each is built in the S4 view, stored to X and read back
   // lane-strided, two rows per step.  X takes them in turns:  Dp -> u -> PRF -> G -> A  (ZAC), Dp -> G -> A (CUSP alone).
   // y is still in the thread's registers (S4 view).
-  f4 ysave[SEP ? R : 1];
-  if constexpr (SEP) {
+  // SEP (CUSP and ZAC optimised separately: two passes): the second pass needs y again.  Kept in sixteen more registers across the
+  // first pass it cost the third workgroup per CU (124 VGPRs); it is REBUILT instead — the raw samples read again (32 KB that left
+  // the L2 a few tens of microseconds ago) and put through the statements of the y loop above, with the wave-row table that is
+  // still in LDS: the same bits.
+  auto rebuild_y = [&]() __attribute__((always_inline)) {
+    const float* w2 = w; const uint16_t* w16_2 = w16;
+    asm volatile("" : "+s"(w2), "+s"(w16_2));
+    load_raw(y, w2, w16_2);
+    const f2 pv = splat(wv(P.bl.from));
+    const float delta = S.misc[MS_DELTA];
+    float t[R], i1[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) ysave[r] = y[r];
-  }
+    for (int r = 0; r < R; ++r) {
+      y[r].xy -= pv; y[r].zw -= pv;
+      t[r] = ((y[r].x + y[r].y) + y[r].z) + y[r].w;   // (c3 of the first pass: the same order of additions)
+      i1[r] = t[r];
+    }
+    LDSP_DPP_GROUP4("v_add_f32_dpp", i1[0], "v_add_f32_dpp", i1[1], "v_add_f32_dpp", i1[2], "v_add_f32_dpp", i1[3]);
+    const float c = P.pz_c, cd = c * delta;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float fi = (float)(4 * (opaque(tid) + NT * r));
+      const float Br = S.scn[2 * R * NW + 4 * wave + r];
+      const float c0 = y[r].x, c1 = c0 + y[r].y, c2 = c1 + y[r].z, c3 = c2 + y[r].w;
+      const f4 xs = (f4){y[r].x - delta, y[r].y - delta, y[r].z - delta, y[r].w - delta};
+      const float ky = fmaf(c, i1[r] - t[r], Br) - cd * (fi + 1.f);
+      y[r].x = xs.x + fmaf(c, c0, ky);
+      y[r].y = xs.y + fmaf(c, c1, ky - cd);
+      y[r].z = xs.z + fmaf(c, c2, ky - 2.f * cd);
+      y[r].w = xs.w + fmaf(c, c3, ky - 3.f * cd);
+    }
+  };
   const float y0 = S.misc[15];
   float* hyl_cz = S.hy + 4 * NH * (R * NW + 1);
   // the sample before each quad (d[i] = y[i] - a*y[i-1]): the previous lane's last one; lane 0: the previous wave-row's, from the table
@@ -1734,7 +1771,8 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         gq = fmaf(q1, gq, d[r][1].y);
         b[r] = gq;
       }
-      s4_exscan_affine_fwd<NT, R>(b, s_in, Z.qp4, Z.qpw, S.part);   // (the wave index as a scalar argument, or the four chains in one statement: five / six registers to scratch, -1.6 % / -3 %)   // barrier inside: the LS reads of Dp are done
+      if constexpr (SEP) s4_exscan_affine_fwd<NT, R>(b, s_in, Z.qp4, Z.qpw, S.part, opaque(tid) >> 6);   // (a wave index of its own: the two passes' lane selects are not shared — through scratch)
+      else s4_exscan_affine_fwd<NT, R>(b, s_in, Z.qp4, Z.qpw, S.part);   // (the wave index as a scalar argument, or the four chains in one statement: five / six registers to scratch, -1.6 % / -3 %)   // barrier inside: the LS reads of Dp are done
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const float g0 = fmaf(q1, s_in[r], d[r][0].x), g1 = fmaf(q1, g0, d[r][0].y), g2 = fmaf(q1, g1, d[r][1].x), g3 = fmaf(q1, g2, d[r][1].y);
@@ -1770,7 +1808,8 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         a = fmaf(q1, a, d[r][0].x);
         b[r] = a;
       }
-      s4_exscan_affine_bwd<NT, R>(b, s_in, Z.qp4, Z.qpw, S.part + R * NW);   // barrier inside: the LS reads of G are done
+      if constexpr (SEP) s4_exscan_affine_bwd<NT, R>(b, s_in, Z.qp4, Z.qpw, S.part + R * NW, opaque(tid) >> 6);
+      else s4_exscan_affine_bwd<NT, R>(b, s_in, Z.qp4, Z.qpw, S.part + R * NW);   // barrier inside: the LS reads of G are done
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const float a3 = fmaf(q1, s_in[r], d[r][1].y), a2 = fmaf(q1, a3, d[r][1].x), a1 = fmaf(q1, a2, d[r][0].y), a0 = fmaf(q1, a1, d[r][0].x);
@@ -1874,8 +1913,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     const float cp_c = S.misc[12], cp_z = S.misc[13];
     cz_pass(T_{}, F_{}, P.cusp, P.zac, cp_c);
     LDSP_BAR_CZ();   // every read of A is done
-#pragma unroll
-    for (int r = 0; r < R; ++r) y[r] = ysave[r];
+    rebuild_y();
     cz_pass(F_{}, T_{}, P.zac, P.zac, cp_z);
   }
   STAMP(23); DSTOP(23);

@@ -1,41 +1,37 @@
-"""dsp_icpc throughput for parameter sets the lean kernel does and does not take: shared CUSP/ZAC geometry (the reference's
-test configuration) vs separately optimised rise / flat-top times per filter (pars_filter), L = 8192.  usage: [n]"""
-import sys, os
+"""Kernel rate of dsp_icpc for the parameter sets beside the headline's, with the kernel each one ran and a hash of its table (so that
+two library builds can be compared bit for bit): trace lengths that do not fill the tile, lengths that are no multiple of four samples,
+optimised Savitzky-Golay windows of 11 ... 27 taps, CUSP and ZAC optimised separately, uint16 input.
+Usage (GPU box): [LDSP_HIP_LIB=build/dev/libldsp_X.so] python tools/gpu_time_icpc_variants.py [n_traces]"""
+import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import legenddsp_jl_amd as ldsp
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-L, us = 8192, ldsp.us
-wf = ldsp.synth.hpge_batch(n, L, device="cuda")
-ctx = ldsp.default_context(); ctx.enable_timing(True)
-cases = {"test configuration (CUSP = ZAC geometry)": {},
-         "separate rise times: cusp rt 4.0 / zac rt 5.5 us": {"cusp": {"rt": 4.0 * us, "ft": 1.5 * us}, "zac": {"rt": 5.5 * us, "ft": 1.5 * us}},
-         "separate flat tops: cusp ft 1.0 / zac ft 2.0 us": {"cusp": {"rt": 5.0 * us, "ft": 1.0 * us}, "zac": {"rt": 5.0 * us, "ft": 2.0 * us}}}
-for name, pf in cases.items():
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+us, ns = ldsp.us, ldsp.ns
+sep = {"cusp": {"rt": 4.0 * us, "ft": 1.5 * us}, "zac": {"rt": 5.5 * us, "ft": 2.0 * us}}
+cases = [("headline", 8192, {}, False), ("L=8000", 8000, {}, False), ("L=8190", 8190, {}, False), ("L=7001", 7001, {}, False),
+         ("SG 180 ns (11 taps)", 8192, {"sg": {"wl": 180.0 * ns}}, False), ("SG 240 ns (15 taps)", 8192, {"sg": {"wl": 240.0 * ns}}, False),
+         ("SG 300 ns (19 taps)", 8192, {"sg": {"wl": 300.0 * ns}}, False), ("SG 350 ns (23 taps)", 8192, {"sg": {"wl": 350.0 * ns}}, False),
+         ("SG 400 ns (25 taps)", 8192, {"sg": {"wl": 400.0 * ns}}, False), ("SG 430 ns (27 taps)", 8192, {"sg": {"wl": 430.0 * ns}}, False),
+         ("separate CUSP / ZAC", 8192, sep, False), ("separate CUSP / ZAC, L=8000", 8000, sep, False),
+         ("separate CUSP / ZAC, SG 300 ns", 8192, dict(sep, sg={"wl": 300.0 * ns}), False), ("uint16 input", 8192, {}, True),
+         ("uint16 input, separate CUSP / ZAC, L=8190", 8190, sep, True)]
+ctx = ldsp.Context(0)
+ctx.enable_timing(True)
+full = ldsp.synth.hpge_batch(n, 8192, device="cuda", seed=3)
+for name, L, pf, u16 in cases:
     p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * us, pf, L, 0.0, 16.0)
-    ldsp.icpc_run(wf, p, ctx); torch.cuda.synchronize()
-    ms = min((ldsp.icpc_run(wf, p, ctx), ctx.last_kernel_ms())[1] for _ in range(3))
-    print(f"{name:55s} {ctx.last_kernel_name():24s} {ms:.3f} ms -> {n / ms * 1e3 / 1e6:.2f} M waveforms/s")
-# uint16 ADC counts: converted in the kernel's load vs a separate cast pass before the float32 kernel
-p = ldsp.lower_icpc(ldsp.reference_test_icpc_config(), 500 * us, {}, L, 0.0, 16.0)
-w16 = wf.round().clamp(0, 65535).to(torch.uint16)
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-def timed(fn):
-    fn(); torch.cuda.synchronize()
-    best = 1e9
-    for _ in range(3):
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); best = min(best, e0.elapsed_time(e1))
-    return best
-t_a = timed(lambda: ldsp.icpc_run(w16, p, ctx))
-t_b = timed(lambda: ldsp.icpc_run(w16.to(torch.float32), p, ctx))
-print(f"uint16 input, converted while loading: {t_a:.3f} ms -> {n / t_a * 1e3 / 1e6:.2f} M waveforms/s;  cast pass + float32 kernel: {t_b:.3f} ms -> {n / t_b * 1e3 / 1e6:.2f} M waveforms/s")
-# BASELINE config 2 (pole-zero + trapezoid) on float32 and on uint16 input, at a batch that does not fit the caches
-n2 = int(sys.argv[2]) if len(sys.argv) > 2 else 524288
-wf2 = ldsp.synth.hpge_batch(65536, L, device="cuda").round().clamp(0, 65535).repeat(n2 // 65536, 1)
-w2_16 = wf2.to(torch.uint16)
-out2 = torch.empty((2, n2), dtype=torch.float32, device="cuda")
-for name, x, bpt in (("float32", wf2, 4 * L + 8), ("uint16", w2_16, 2 * L + 8)):
-    ldsp.icpc_pz_trap_run(x, p, ctx, out=out2); torch.cuda.synchronize()
-    ms = min((ldsp.icpc_pz_trap_run(x, p, ctx, out=out2), ctx.last_kernel_ms())[1] for _ in range(5))
-    print(f"pole-zero + trapezoid, {name} input, {n2} traces: {ctx.last_kernel_name()} {ms:.3f} ms -> {n2 / ms * 1e3 / 1e6:.1f} M waveforms/s, "
-          f"{n2 * bpt / ms * 1e3 / 1e12:.2f} TB/s = {n2 * bpt / ms * 1e3 / 8e12 * 100:.0f} % of 8 TB/s ({bpt} B per trace)")
+    wf = full[:, :L].contiguous()
+    if u16:
+        wf = wf.round().clamp(0, 65535).to(torch.uint16)
+    out = torch.empty((n, len(ldsp._abi.ICPC_COLS)), dtype=torch.float32, device="cuda")
+    ms = []
+    for it in range(7):
+        ldsp.icpc_run(wf, p, ctx, out=out)
+        ctx.synchronize()
+        ms.append(ctx.last_kernel_ms())
+    ms = sorted(ms[2:])
+    h = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12]
+    print(f"{name:44s} {ctx.last_kernel_name():26s} min {ms[0]:7.3f} ms  median {ms[len(ms) // 2]:7.3f} ms  {n / ms[len(ms) // 2] / 1e3:6.2f} M waveforms/s  table {h}", flush=True)
+    del wf, out
