@@ -13,20 +13,31 @@ with open(os.path.join(dst, f"{tag}_bench.json"), "w") as f:
     f.write(line + "\n")
 bench = json.loads(line)
 shutil.copy(os.path.join(src, "stats", "p_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
-# the same run's kernel trace without each kernel's FIRST launch (cold instruction cache / clocks): what the bench's timed steps see
+# the same run's kernel trace without each kernel's FIRST launch (cold instruction cache / clocks): what the bench's timed steps see;
+# and the launches in the STEADY state apart: the GPU clock ramps for ~50 ms after an idle gap (profiles/r04_pz_trap_launch_spread.txt),
+# so a launch counts as steady when the library's kernels have been running back to back (gaps < 2 ms) for at least 60 ms before it
 kt = os.path.join(src, "stats", "p_kernel_trace.csv")
 if os.path.exists(kt):
     per = collections.defaultdict(list)
-    for r in csv.DictReader(open(kt)):
-        if r["Kernel_Name"].startswith("void ldsp::"):
-            per[(r["Kernel_Name"].replace("void ", "").split("(")[0], int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]))].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    rows = [r for r in csv.DictReader(open(kt)) if r["Kernel_Name"].startswith("void ldsp::")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    busy_since, prev_end = None, None
+    for r in rows:
+        st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if prev_end is None or st - prev_end > 2_000_000:
+            busy_since = st
+        prev_end = en
+        key = (r["Kernel_Name"].replace("void ", "").split("(")[0], int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]))
+        per[key].append((st, en - st, st - busy_since >= 60_000_000))
     with open(os.path.join(dst, f"{tag}_bench_kernel_stats_warm.csv"), "w") as g:
-        g.write("kernel,traces,launches,first_launch_ns,warm_launches,warm_avg_ns,warm_min_ns,warm_max_ns\n")
+        g.write("kernel,traces,launches,first_launch_ns,warm_launches,warm_avg_ns,warm_min_ns,warm_max_ns,steady_launches,steady_avg_ns,steady_min_ns,steady_max_ns\n")
         for (k, nd), v in sorted(per.items()):
             v.sort()
             d = [x[1] for x in v]
             w = d[1:] if len(d) > 1 else d
-            g.write(f'"{k}",{nd},{len(d)},{d[0]},{len(w)},{sum(w) / len(w):.0f},{min(w)},{max(w)}\n')
+            sd = [x[1] for x in v if x[2]]
+            steady = f"{len(sd)},{sum(sd) / len(sd):.0f},{min(sd)},{max(sd)}" if sd else "0,,,"
+            g.write(f'"{k}",{nd},{len(d)},{d[0]},{len(w)},{sum(w) / len(w):.0f},{min(w)},{max(w)},{steady}\n')
 for t in ("gpu_time_grid", "gpu_time_compressed", "gpu_time_multi_intersect"):
     ks = os.path.join(src, f"stats_{t}", "p_kernel_stats.csv")
     if os.path.exists(ks):
