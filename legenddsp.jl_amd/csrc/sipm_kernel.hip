@@ -26,6 +26,7 @@ struct SipmDev {
   double t_first64, dt64;   // the time axis as given (trigger positions are composed in double)
   int32_t trunc_from, trunc_until;
   float sg_c[LDSP_MAX_SG_PTS];  // correlation taps
+  float sg_cs[LDSP_MAX_SG_PTS]; // their suffix sums, cs[m] = sum_{i >= m} c[i]: the taps of the integrated filter (k_sipm_s4)
   int32_t sg_mintot, sg_maxtot;
   float sg_min_thr, sg_max_thr, sg_nsigma, sg_min_dc, sg_max_dc, sg_nsigma_dc;
   float pz_c;
@@ -130,8 +131,22 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
   __syncthreads();
   if (P.dbg_stop == 4) return;
   const float minx = fminf(sc.f[1], 0.f);
-  // IntegratorFilter(gain = 1): I = cumsum(g) in place   :108-109
-  tb::prefix_sum_inplace(B, ng, sc);
+  // IntegratorFilter(gain = 1) on g   :108-109, telescoped as in k_sipm_s4 (sipm_s4.inc: no running sum of rounded values):
+  //   I[k] = F(k) - F(-1),  F(k) = sum_{m=1}^{np-1} cs[m] (x[k+m] - x[0]),  cs[m] = sum_{i >= m} c[i];  the samples are read again into A
+  if (P.in_u16) tb::load_trace_u16(reinterpret_cast<const uint16_t*>(wf) + b * (size_t)L, A, L);
+  else tb::load_trace(wf + b * (size_t)L, A, L);
+  for (int i = L + tid; i < pad4(L); i += NT) A[i] = 0.f;
+  __syncthreads();
+  {
+    const float x0 = A[0];
+    float f0 = 0.f;
+    for (int m = 1; m < np; ++m) f0 = fmaf(P.sg_cs[m], A[m - 1] - x0, f0);
+    for (int k = tid; k < pad4(L); k += NT) {
+      float acc = -f0;
+      if (k < ng) for (int m = 1; m < np; ++m) acc = fmaf(P.sg_cs[m], A[k + m] - x0, acc);
+      B[k] = (k < ng) ? acc : 0.f;
+    }
+  }
   __syncthreads();
   {  // signalstats on the integrated trace :112-115 (the init = 0 quirk: SURVEY a2)
     const float time_min = tg, d3 = 3.f * P.dt;
@@ -261,6 +276,7 @@ static int sipm_run_impl(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_sip
   std::vector<double> cc;
   if (!hm::sg_corr_coeffs(p->sg_npts, p->sg_degree, 1, cc)) return ldsp_fail(LDSP_ERR_INVALID_ARG, "Savitzky-Golay coefficients");
   for (int i = 0; i < p->sg_npts; ++i) d.sg_c[i] = (float)cc[i];
+  { double suf = 0.0; for (int i = p->sg_npts - 1; i >= 0; --i) { suf += cc[i]; d.sg_cs[i] = (float)suf; } }
   d.sg_mintot = p->sg_mintot; d.sg_maxtot = p->sg_maxtot;
   d.sg_min_thr = (float)p->sg_min_thr; d.sg_max_thr = (float)p->sg_max_thr; d.sg_nsigma = (float)p->sg_nsigma;
   d.sg_min_dc = (float)p->sg_min_dc_thr; d.sg_max_dc = (float)p->sg_max_dc_thr; d.sg_nsigma_dc = (float)p->sg_nsigma_dc;

@@ -10,14 +10,21 @@ import torch
 import legenddsp_jl_amd as ldsp
 
 
-def icpc_case(seed, it):
-    """-> (L, dt, cfg, tau, pars_filter, noise, description).  Filter parameters, tau, window placement, trace length."""
+def icpc_case(seed, it, wide=False):
+    """-> (L, dt, cfg, tau, pars_filter, noise, description).  Filter parameters, tau, window placement, trace length.
+    wide (round 4; the cases without it are unchanged): trace lengths that are no multiple of four samples and optimised
+    Savitzky-Golay windows from the whole of the reference's scan grid (up to 350 ns: 23 taps), one step beyond it (400 ns: 25
+    taps, the lean kernel's limit) and past it (430 ns: the generic kernel)."""
     rng = np.random.default_rng([seed, it])
     us = ldsp.us
     L = int(rng.choice([8192, 8192, 6000, 7300, 16384]))
     dt = 16.0
     pf = {"trap": {"rt": float(rng.uniform(2, 12)) * us, "ft": float(rng.uniform(0.5, 4)) * us},
           "sg": {"wl": float(rng.choice([80, 100, 132, 180, 200])) * ldsp.ns}}
+    if wide:
+        rw = np.random.default_rng([seed, it, 77])
+        L = int(rw.choice([8190, 8191, 7301, 6002, 4099, 5003, 8189]))
+        pf["sg"]["wl"] = float(rw.choice([62, 126, 222, 254, 318, 350, 400, 430])) * ldsp.ns
     crt, cft = float(rng.uniform(2, 8)) * us, float(rng.uniform(0.5, 3)) * us
     pf["cusp"] = {"rt": crt, "ft": cft}
     zac_same = bool(rng.random() < 0.6)

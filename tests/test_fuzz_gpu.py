@@ -33,6 +33,27 @@ def test_icpc_randomised_configuration(orc, seed, it):
     assert worst <= parity.FLIP_FRAC, descr + "\n" + "\n".join(bad)
 
 
+@pytest.mark.parametrize("it", range(8))
+def test_icpc_randomised_configuration_odd_lengths_and_long_windows(orc, it):
+    """The same generator with trace lengths that are no multiple of four samples (4-byte aligned rows, the last quad of a trace read
+    sample by sample) and optimised Savitzky-Golay windows of up to 27 taps (25: the streaming form of the lean kernel) — what the
+    lean kernel admits since round 4 — with shared and separate CUSP / ZAC (the second pass rebuilds y)."""
+    n = 256
+    L, dt, cfg, tau, pf, noise, descr = fuzz_cases.icpc_case(3, it, wide=True)
+    p = ldsp.lower_icpc(cfg, tau, pf, L, 0.0, dt)
+    wf = fuzz_cases.icpc_traces(n, L, it, noise)
+    tab = ldsp.icpc_run(wf, p)
+    torch.cuda.synchronize()
+    name = ldsp.default_context().last_kernel_name()
+    assert name == ("lean3::icpc_lean3_kernel" if p.sg_npts[0] <= 25 else "icpc_kernel"), (descr, name)
+    gpu = {k: v.cpu().numpy() for k, v in ldsp.table_columns(tab).items()}
+    host = wf.cpu().numpy()
+    ora = orc.dsp_icpc(host, p, nthreads=16, strict=False)
+    lines, worst = parity.compare(gpu, ora, wf=host, params=p, orc=orc)
+    bad = [l for l in lines if f"bad=0/{n}" not in l]
+    assert worst <= parity.FLIP_FRAC, descr + " sg_taps=" + str(p.sg_npts[0]) + "\n" + "\n".join(bad)
+
+
 @pytest.mark.parametrize("it", range(6))
 def test_sipm_randomised_configuration(orc, it):
     n = 192

@@ -21,7 +21,7 @@ for it in range(nconf):
     wf = fuzz_cases.sipm_traces(n, L, it, noise, mean_pulses)
     sc, trig = ldsp.sipm_run(wf, p); torch.cuda.synchronize()
     ora = orc.dsp_sipm(wf.cpu().numpy(), p, nthreads=16)
-    msgs = fuzz_cases.sipm_compare(sc, trig, ora, n)
+    msgs = fuzz_cases.sipm_compare(sc, trig, ora, n, wf, p, orc)
     tot_bad += len(msgs)
-    print(f"[{it}] {descr}: " + ("; ".join(msgs) if msgs else "all within tolerance"))
+    print(f"[{it}] {descr}: " + ("; ".join(msgs) if msgs else "all within tolerance"), flush=True)
 print("entries with any disagreement:", tot_bad)

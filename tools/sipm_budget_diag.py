@@ -8,10 +8,11 @@ import numpy as np, torch
 import legenddsp_jl_amd as ldsp
 from oracle import oracle as orc
 import fuzz_cases, sipm_budget
+seed = int(os.environ.get("FUZZ_SEED", "1"))
 its = [int(a) for a in sys.argv[1:]] or list(range(6))
 n = 192
 for it in its:
-    L, cfg, pf, noise, mean_pulses, descr = fuzz_cases.sipm_case(1, it)
+    L, cfg, pf, noise, mean_pulses, descr = fuzz_cases.sipm_case(seed, it)
     p = ldsp.lower_sipm(cfg, pf, L, 0.0, 16.0)
     wf = fuzz_cases.sipm_traces(n, L, it, noise, mean_pulses)
     sc, trig = ldsp.sipm_run(wf, p)
