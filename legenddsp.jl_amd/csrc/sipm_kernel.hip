@@ -179,38 +179,63 @@ __global__ void __launch_bounds__(1024) k_sipm(const float* __restrict__ wf, Sip
   }
   if (P.dbg_stop == 6) return;
   // InvCRFilter(pz_tau) on I, then TrapezoidalChargeFilter(rt, ft)   :124-129
-  for (int i = tid; i < pad4(L); i += NT) A[i] = (i < ng) ? B[i] : 0.f;
-  __syncthreads();
-  tb::prefix_sum_inplace(A, ng, sc);
-  __syncthreads();
-  for (int i = tid; i < pad4(L); i += NT) A[i] = (i < ng) ? B[i] + P.pz_c * A[i] : 0.f;  // P
-  __syncthreads();
   const int flen = P.trap.navg + P.trap.ngap + P.trap.navg2, nt = ng - flen + 1;
   const float tt = tg + P.dt * (float)(flen - 1);
   const double tt64 = fma(P.dt64, (double)(flen - 1), tg64);
-  {
-    const float i1 = 1.f / (float)P.trap.navg, i2 = 1.f / (float)P.trap.navg2;
-    // SiPM shaping times are a few samples: sum the windows directly (a difference of float
-    // prefix sums would carry ulp(cumsum) / navg of error into the MAD threshold)
-    const bool direct = P.trap.navg <= 16 && P.trap.navg2 <= 16;
-    if (!direct) {
-      tb::prefix_sum_inplace(A, ng, sc);  // S = cumsum(P)
-      __syncthreads();
+  if (P.trap.navg == P.trap.navg2) {
+    // equal legs (what TrapezoidalChargeFilter(rt, ft) builds): difference-first as in k_sipm_s4 (sipm_s4.inc) — the pole-zero corrected
+    // trace Pz = I + c cumsum(I) is never formed:  tr[k] = (1/n) sum_{j<n} E[k+j],  E[k] = Pz[k+o2] - Pz[k] = I[k+o2] - I[k] + c sum_{t=k+1}^{k+o2} I[t]
+    const int o2 = P.trap.navg + P.trap.ngap, nn = P.trap.navg;
+    const float inv = 1.f / (float)nn;
+    for (int k = tid; k < pad4(L); k += NT) {
+      float v = 0.f;
+      if (k + o2 < ng) {
+        float w = 0.f;
+        for (int t = 1; t <= o2; ++t) w += B[k + t];
+        v = fmaf(P.pz_c, w, B[k + o2] - B[k]);
+      }
+      A[k] = v;   // E
     }
+    __syncthreads();
     for (int k = tid; k < pad4(L); k += NT) {
       float v = 0.f;
       if (k < nt) {
-        if (direct) {
-          float a = 0.f, bb = 0.f;
-          for (int j = 0; j < P.trap.navg2; ++j) a += A[k + P.trap.navg + P.trap.ngap + j];
-          for (int j = 0; j < P.trap.navg; ++j) bb += A[k + j];
-          v = a * i2 - bb * i1;
-        } else {
-          const float s0 = (k > 0) ? A[k - 1] : 0.f;
-          v = (A[k + flen - 1] - A[k + P.trap.navg + P.trap.ngap - 1]) * i2 - (A[k + P.trap.navg - 1] - s0) * i1;
-        }
+        for (int j = 0; j < nn; ++j) v += A[k + j];
+        v *= inv;
       }
       B[k] = v;
+    }
+  } else {
+    for (int i = tid; i < pad4(L); i += NT) A[i] = (i < ng) ? B[i] : 0.f;
+    __syncthreads();
+    tb::prefix_sum_inplace(A, ng, sc);
+    __syncthreads();
+    for (int i = tid; i < pad4(L); i += NT) A[i] = (i < ng) ? B[i] + P.pz_c * A[i] : 0.f;  // P
+    __syncthreads();
+    {
+      const float i1 = 1.f / (float)P.trap.navg, i2 = 1.f / (float)P.trap.navg2;
+      // SiPM shaping times are a few samples: sum the windows directly (a difference of float
+      // prefix sums would carry ulp(cumsum) / navg of error into the MAD threshold)
+      const bool direct = P.trap.navg <= 16 && P.trap.navg2 <= 16;
+      if (!direct) {
+        tb::prefix_sum_inplace(A, ng, sc);  // S = cumsum(P)
+        __syncthreads();
+      }
+      for (int k = tid; k < pad4(L); k += NT) {
+        float v = 0.f;
+        if (k < nt) {
+          if (direct) {
+            float a = 0.f, bb = 0.f;
+            for (int j = 0; j < P.trap.navg2; ++j) a += A[k + P.trap.navg + P.trap.ngap + j];
+            for (int j = 0; j < P.trap.navg; ++j) bb += A[k + j];
+            v = a * i2 - bb * i1;
+          } else {
+            const float s0 = (k > 0) ? A[k - 1] : 0.f;
+            v = (A[k + flen - 1] - A[k + P.trap.navg + P.trap.ngap - 1]) * i2 - (A[k + P.trap.navg - 1] - s0) * i1;
+          }
+        }
+        B[k] = v;
+      }
     }
   }
   __syncthreads();
