@@ -462,7 +462,8 @@ static bool icpc_lean_applies(const ldsp_ctx* c, bool full_tile = false) {
       H.L <= 8 * H.NT || (full_tile && H.L != 16 * H.NT) ||   // (more than half the tile: its first two rows are in the trace)
       H.cusp_mode != 1 || !H.t0inv_same || H.tx_mintot > 2 || H.sg_npts[0] > 25 || sg_fixed > 13)
     return false;
-  const double rail = std::max(std::fabs((double)H.sat_high), std::fabs((double)H.sat_low)) * (double)H.L;
+  // (the rails bound the signal; rails left at zero — saturation not configured — are taken as a 16-bit range, not as "no signal")
+  const double rail = std::max(std::max(std::fabs((double)H.sat_high), std::fabs((double)H.sat_low)), 65535.0) * (double)H.L;
   const double drop = std::max(std::fabs((double)H.cusp.w_last) * H.cusp.eps, std::fabs((double)H.zac.w_last) * H.zac.eps) * rail;
   if (H.cz_shared && H.zac.zf_n <= 0) return false;
   return drop < 1e-2 && icpc_lean3_smem_bytes(H.NT, std::max(H.cusp.Lf, H.zac.Lf)) <= 80640;   // (<= 53 760: three workgroups per CU)
