@@ -142,7 +142,7 @@ def test_sipm_reference_fixture_properties():
     assert torch.equal(res2.threshold, res.threshold) and torch.equal(res2.trig_pos.values, res.trig_pos.values)
 
 
-@pytest.mark.parametrize("L", [6250, 5000, 3500, 12001])
+@pytest.mark.parametrize("L", [6250, 5000, 3500, 12001, 3400, 4092, 3999, 8000])   # (3400 ... 4092: the 128-thread tile, not full)
 def test_sipm_matches_oracle_odd_length(orc, L):
     """Traces that do not fill the register kernel's tile (rows 16-byte aligned or not)."""
     n = 32
