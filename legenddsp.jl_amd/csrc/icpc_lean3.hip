@@ -385,6 +385,12 @@ __device__ __forceinline__ uint32_t nib_le(f4 v, float t) {
 #ifndef LDSP_L3_WPS
 #define LDSP_L3_WPS 6
 #endif
+#ifndef LDSP_L3_BFLY   // 1: the wave reductions of the sweeps' and the current windows' maxima as butterflies (wave_prims.hpp: LDSP_BFLY4): +1.5 %, same bits
+#define LDSP_L3_BFLY 1
+#endif
+#ifndef LDSP_L3_BFLY_SUMS   // 1: also the small groups (tail sums, CUSP / ZAC maxima, raw extremes): no further gain measured (their wait states eat it), sums change their last bits
+#define LDSP_L3_BFLY_SUMS 0
+#endif
 #ifndef LDSP_L3_TAB0   // 1: the cross-wave tables of the first exchange are computed by wave 0 only (see there)
 #define LDSP_L3_TAB0 1
 #endif
@@ -515,7 +521,14 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     }
     float s1, s2, sx;
     wacc_lane<NT>(a, tid, (float)P.bl.ic, &s1, &s2, &sx);
+#if LDSP_L3_BFLY_SUMS
+    // (the three sums in the order config 2's kernel takes them: blmean bit for bit; the extremes as a butterfly: lane 31: max, lane 63: -min)
+    LDSP_DPP_GROUP3("v_add_f32_dpp", s1, "v_add_f32_dpp", s2, "v_add_f32_dpp", sx);
+    rmin = -rmin;
+    LDSP_BFLY2("v_max_f32", "v_max_f32_dpp", rmax, rmin);
+#else
     LDSP_DPP_GROUP5("v_add_f32_dpp", s1, "v_add_f32_dpp", s2, "v_add_f32_dpp", sx, "v_max_f32_dpp", rmax, "v_min_f32_dpp", rmin);
+#endif
 #ifdef LDSP_WHATIF_S16
     LDSP_DPP_GROUP1("v_add_f32_dpp", i1[0]);
 #else
@@ -532,10 +545,17 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     for (int r = 0; r < R; ++r) ex2[r] = i2[r] - ex2[r];
     if (lane == 63) {
       S.wred[0 * NW + wave] = s1; S.wred[1 * NW + wave] = s2; S.wred[2 * NW + wave] = sx;
+#if LDSP_L3_BFLY_SUMS
+      S.wred[4 * NW + wave] = -rmax;   // (lane 63 of the butterfly: -min)
+#else
       S.wred[3 * NW + wave] = rmax; S.wred[4 * NW + wave] = rmin;
+#endif
       *reinterpret_cast<f4*>(&S.part[4 * wave]) = (f4){i1[0], i1[1], i1[2], i1[3]};            // [wave][r]
       *reinterpret_cast<f4*>(&S.part[R * NW + 4 * wave]) = (f4){i2[0], i2[1], i2[2], i2[3]};
     }
+#if LDSP_L3_BFLY_SUMS
+    if (lane == 31) S.wred[3 * NW + wave] = rmax;   // (lane 31 of the butterfly: max)
+#endif
   }
   STAMP(1); DSTOP(1);
   LDSP_BAR_MAIN();
@@ -683,11 +703,19 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
         wacc_quad(a, d0, d1, r);
       }
       wacc_lane<NT>(a, tid, (float)P.tail.ic, &l1, &l2, &lx);
+#if LDSP_L3_BFLY_SUMS
+      float z0 = 0.f;
+      LDSP_BFLY4("v_add_f32", "v_add_f32_dpp", l1, l2, lx, z0);   // totals in lanes 15 / 47 / 31 of l1
+      LDSP_DPP_GROUP1("v_min_f32_dpp", tmin);
+      if ((lane & 15) == 15 && lane != 63) S.wsum[(W_TAIL + (lane == 15 ? 0 : lane == 47 ? 1 : 2)) * NW + wave] = l1;
+      if (lane == 63 && tmin <= 0.f) S.sl->isum[IS_TAILBAD] = 1;   // any wave may set it (same value)
+#else
       LDSP_DPP_GROUP4("v_add_f32_dpp", l1, "v_add_f32_dpp", l2, "v_add_f32_dpp", lx, "v_min_f32_dpp", tmin);
       if (lane == 63) {
         S.wsum[(W_TAIL + 0) * NW + wave] = l1; S.wsum[(W_TAIL + 1) * NW + wave] = l2; S.wsum[(W_TAIL + 2) * NW + wave] = lx;
         if (tmin <= 0.f) S.sl->isum[IS_TAILBAD] = 1;   // any wave may set it (same value)
       }
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
 #if LDSP_L3_TAB0 && !defined(LDSP_WHATIF_S16)
@@ -977,6 +1005,33 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
   }
   // ---- reductions of the sweeps and of the tail sums (before the SG pass: fourteen registers less across it)
   {
+#if LDSP_L3_BFLY
+    // (maxima by butterfly, wave_prims.hpp: four values in ten instructions, totals in lanes 15 / 47 / 31 / 63 = mx0 / mx1 / mx2 / -mn0,
+    // each of which posts its own; max and min do not depend on the order: the same bits)
+    float nm0 = -mn0, nm2 = -mn2;   // max(trap(-y)) = -min(trap(y))
+    LDSP_BFLY4("v_max_f32", "v_max_f32_dpp", mx0, mx1, mx2, nm0);
+#if LDSP_L3_BFLY_SUMS
+    float z0 = 0.f;
+    LDSP_BFLY4("v_add_f32", "v_add_f32_dpp", t1, t2, tx, z0);   // totals in lanes 15 / 47 / 31 of t1
+    LDSP_DPP_GROUP1("v_max_f32_dpp", nm2);
+#else
+    LDSP_DPP_GROUP4("v_max_f32_dpp", nm2, "v_add_f32_dpp", t1, "v_add_f32_dpp", t2, "v_add_f32_dpp", tx);
+#endif
+    wave_argmax(bo_v, bo_i);
+    if ((lane & 15) == 15) {
+      atomicMax(&S.sl->fmx[lane == 15 ? FX_F0 : lane == 47 ? FX_F1 : lane == 31 ? FX_F2 : FX_F0I], ford(mx0));
+#if LDSP_L3_BFLY_SUMS
+      if (lane != 63) S.wsum[(W_PZ + (lane == 15 ? 0 : lane == 47 ? 1 : 2)) * NW + wave] = t1;
+#endif
+    }
+    if (lane == 63) {
+      atomicMax(&S.sl->fmx[FX_F2I], ford(nm2));
+      atomicMax(&S.sl->vi[VI_OPT], pack_vi(bo_v, bo_i));
+#if !LDSP_L3_BFLY_SUMS
+      S.wsum[(W_PZ + 0) * NW + wave] = t1; S.wsum[(W_PZ + 1) * NW + wave] = t2; S.wsum[(W_PZ + 2) * NW + wave] = tx;
+#endif
+    }
+#else
     LDSP_DPP_GROUP8("v_max_f32_dpp", mx0, "v_max_f32_dpp", mx1, "v_max_f32_dpp", mx2, "v_min_f32_dpp", mn0, "v_min_f32_dpp", mn2, "v_add_f32_dpp", t1, "v_add_f32_dpp", t2, "v_add_f32_dpp", tx);
     wave_argmax(bo_v, bo_i);
     if (lane == 63) {
@@ -988,6 +1043,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       atomicMax(&S.sl->vi[VI_OPT], pack_vi(bo_v, bo_i));
       S.wsum[(W_PZ + 0) * NW + wave] = t1; S.wsum[(W_PZ + 1) * NW + wave] = t2; S.wsum[(W_PZ + 2) * NW + wave] = tx;
     }
+#endif
   }
   LDSP_BAR_MAIN();   // every read of T is done
   // ---- Savitzky-Golay derivatives, current maxima (dsp_icpc.jl:181-186): g[k] = sum_i c[i] y[k+i] (valid mode, trailing time
@@ -1123,9 +1179,36 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     }
   STAMP(6); DSTOP(6); LDSP_PROBE();
   // ---- the SG pass's own reductions
+#if LDSP_L3_BFLY_SUMS
+  LDSP_BFLY2("v_add_f32", "v_add_f32_dpp", g_s1, g_s2);   // totals in lanes 31 / 63 of g_s1
+  LDSP_DPP_GROUP1("v_max_f32_dpp", gmax);
+#else
   LDSP_DPP_GROUP3("v_max_f32_dpp", gmax, "v_add_f32_dpp", g_s1, "v_add_f32_dpp", g_s2);
+#endif
   {
     float v0 = bv[0], v1 = bv[1], v2 = bv[2], v3 = bv[3];
+#if LDSP_L3_BFLY
+    // (the four current-window maxima together, then the first index of each: totals in lanes 15 / 47 / 31 / 63 = filter 0 / 1 / 2 / 3,
+    // each of which posts its own packed (value, index))
+    LDSP_BFLY4("v_max_f32", "v_max_f32_dpp", v0, v1, v2, v3);
+    const float m0 = readlane_f(v0, 15), m1 = readlane_f(v0, 47), m2 = readlane_f(v0, 31), m3 = readlane_f(v0, 63);
+    uint32_t k0 = (bv[0] == m0) ? (uint32_t)bi[0] : 0x7fffffffu, k1 = (bv[1] == m1) ? (uint32_t)bi[1] : 0x7fffffffu,
+             k2 = (bv[2] == m2) ? (uint32_t)bi[2] : 0x7fffffffu, k3 = (bv[3] == m3) ? (uint32_t)bi[3] : 0x7fffffffu;
+    LDSP_BFLY4("v_min_u32", "v_min_u32_dpp", k0, k1, k2, k3);
+    if ((lane & 15) == 15) {
+      const int f = lane == 15 ? 0 : lane == 47 ? 1 : lane == 31 ? 2 : 3;
+      if (k0 != 0x7fffffffu) atomicMax(&S.sl->vi[VI_CUR0 + f], pack_vi(f == 0 ? m0 : f == 1 ? m1 : f == 2 ? m2 : m3, (int)k0));
+    }
+#if LDSP_L3_BFLY_SUMS
+    if (lane == 63) atomicMax(&S.sl->fmx[FX_G], ford(gmax));
+    if ((lane & 31) == 31) S.wsum[(W_SGB + (lane >> 5)) * NW + wave] = g_s1;
+#else
+    if (lane == 63) {
+      atomicMax(&S.sl->fmx[FX_G], ford(gmax));
+      S.wsum[(W_SGB + 0) * NW + wave] = g_s1; S.wsum[(W_SGB + 1) * NW + wave] = g_s2;
+    }
+#endif
+#else
     LDSP_DPP_GROUP4("v_max_f32_dpp", v0, "v_max_f32_dpp", v1, "v_max_f32_dpp", v2, "v_max_f32_dpp", v3);
     uint32_t k0 = (bv[0] == readlane_f(v0, 63)) ? (uint32_t)bi[0] : 0x7fffffffu, k1 = (bv[1] == readlane_f(v1, 63)) ? (uint32_t)bi[1] : 0x7fffffffu,
              k2 = (bv[2] == readlane_f(v2, 63)) ? (uint32_t)bi[2] : 0x7fffffffu, k3 = (bv[3] == readlane_f(v3, 63)) ? (uint32_t)bi[3] : 0x7fffffffu;
@@ -1138,6 +1221,7 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
       if (k3 != 0x7fffffffu) atomicMax(&S.sl->vi[VI_CUR3], pack_vi(v3, (int)k3));
       S.wsum[(W_SGB + 0) * NW + wave] = g_s1; S.wsum[(W_SGB + 1) * NW + wave] = g_s2;
     }
+#endif
   }
   }
   STAMP(7); DSTOP(7);
@@ -1869,11 +1953,20 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
           if (inz) pz_ = est_weight(P.sig_est, S.estB, lz, ew.w) * vz_;
         }
       }
+#if LDSP_L3_BFLY_SUMS
+      LDSP_BFLY2("v_add_f32", "v_add_f32_dpp", pc, pz_);      // totals in lanes 31 (CUSP) / 63 (ZAC)
+      LDSP_BFLY2("v_max_f32", "v_max_f32_dpp", mxc, mxz);
+      if ((lane & 31) == 31) {
+        const bool zz = lane == 63;
+        if (zz ? WZ : WC) { S.wsum[(W_CZ + (zz ? 1 : 0)) * NW + wave] = pc; atomicMax(&S.sl->fmx[zz ? FX_ZAC : FX_CUSP], ford(mxc)); }
+      }
+#else
       LDSP_DPP_GROUP4("v_add_f32_dpp", pc, "v_add_f32_dpp", pz_, "v_max_f32_dpp", mxc, "v_max_f32_dpp", mxz);
       if (lane == 63) {
         if (WC) { S.wsum[(W_CZ + 0) * NW + wave] = pc; atomicMax(&S.sl->fmx[FX_CUSP], ford(mxc)); }
         if (WZ) { S.wsum[(W_CZ + 1) * NW + wave] = pz_; atomicMax(&S.sl->fmx[FX_ZAC], ford(mxz)); }
       }
+#endif
     }
     LDSP_BAR_CZ();
     {

@@ -209,6 +209,28 @@ __device__ __forceinline__ void put_ballots(uint32_t& acc, unsigned long long a,
 // maximum / minimum and lane l the inclusive scan (sums).
 // (generated: ONE asm statement per group — all six steps — so that neither the scheduler nor the register allocator can put a
 // copy or a reload between a step's write and the next step's DPP read; the hazard recogniser does not look inside inline asm)
+// ---- butterfly reductions (round 4): several values reduced over the wave TOGETHER.  v_permlane32_swap_b32 a, b exchanges the upper half of a
+// with the lower half of b, so OP(a, b) afterwards holds 32 partials of a in lanes 0-31 and 32 partials of b in lanes 32-63; v_permlane16_swap_b32
+// does the same for the odd rows of its first operand and the even rows of its second.  Four values: 3 swaps + 3 OPs + 4 DPP steps inside a
+// row (ten instructions where four separate reductions take 24); the TOTALS end in the last lane of each row of `a`:
+//   lane 15: a,   lane 31: c,   lane 47: b,   lane 63: d.
+// Two values: 1 swap + 1 OP + 5 DPP steps; totals in lane 31 (a) and lane 63 (b) of `a`.  Only for order-independent OPs where bits matter
+// (max / min): a sum's rounding depends on the order.  OP / OPD: the plain and the DPP mnemonic ("v_max_f32" / "v_max_f32_dpp").
+// (s_nop: a VALU result is not read by a lane-crossing instruction in the next two issue slots.)
+#define LDSP_BFLY4(OP, OPD, a, b, c, d) \
+  asm volatile( \
+    "s_nop 1\n\t" "v_permlane32_swap_b32 %0, %1\n\t" "v_permlane32_swap_b32 %2, %3\n\t" "s_nop 1\n\t" \
+    OP " %0, %0, %1\n\t" OP " %2, %2, %3\n\t" "s_nop 1\n\t" "v_permlane16_swap_b32 %0, %2\n\t" "s_nop 1\n\t" OP " %0, %0, %2\n\t" "s_nop 1\n\t" \
+    OPD " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" "s_nop 1\n\t" OPD " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" "s_nop 1\n\t" \
+    OPD " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" "s_nop 1\n\t" OPD " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" \
+    : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define LDSP_BFLY2(OP, OPD, a, b) \
+  asm volatile( \
+    "s_nop 1\n\t" "v_permlane32_swap_b32 %0, %1\n\t" "s_nop 1\n\t" OP " %0, %0, %1\n\t" "s_nop 1\n\t" \
+    OPD " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" "s_nop 1\n\t" OPD " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" "s_nop 1\n\t" \
+    OPD " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" "s_nop 1\n\t" OPD " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" "s_nop 1\n\t" \
+    OPD " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" \
+    : "+v"(a), "+v"(b))
 #define LDSP_DPP_GROUP1(O0, v0) \
   asm volatile( \
     "s_nop 1\n\t" O0 " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t" \
