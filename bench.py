@@ -189,7 +189,7 @@ def timed(env, args, step, finish=lambda: None):
 #   "instruction_stream": every instruction the shipped kernel issues (SQ_INSTS per wave, all kinds, profiles/r04_lean3_phase_insts.txt)
 #   at the cheapest issue price measured on this chip (2.08 cycles per instruction and SIMD, v_fmac at >= 4 waves per SIMD):
 #   2.4e9 * 1024 SIMDs / (8 waves * INSTS_PER_WAVE * 2.08).  The kernel cannot exceed it without issuing fewer instructions.
-INSTS_PER_WAVE_ICPC = 5940
+INSTS_PER_WAVE_ICPC = 5794
 ISSUE_CEILING_ICPC = {"algorithmic": 65.0e6, "instruction_stream": 2.4e9 * 1024 / (8 * INSTS_PER_WAVE_ICPC * 2.08)}
 
 
