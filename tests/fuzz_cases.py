@@ -23,7 +23,7 @@ def icpc_case(seed, it, wide=False):
           "sg": {"wl": float(rng.choice([80, 100, 132, 180, 200])) * ldsp.ns}}
     if wide:
         rw = np.random.default_rng([seed, it, 77])
-        L = int(rw.choice([8190, 8191, 7301, 6002, 4099, 5003, 8189]))
+        L = int(rw.choice([8190, 8191, 7301, 6002, 4099, 5003, 8189])) if wide != 4 else int(rw.choice([8188, 8184, 7300, 6004, 4100, 5004, 8180]))   # (wide = 4: the same sweep with rows that ARE 16-byte aligned, as a control)
         pf["sg"]["wl"] = float(rw.choice([62, 126, 222, 254, 318, 350, 400, 430])) * ldsp.ns
     crt, cft = float(rng.uniform(2, 8)) * us, float(rng.uniform(0.5, 3)) * us
     pf["cusp"] = {"rt": crt, "ft": cft}

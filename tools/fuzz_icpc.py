@@ -11,7 +11,7 @@ import parity, fuzz_cases
 orc.build()
 nconf = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+wide = (4 if sys.argv[3] == "wide4" else sys.argv[3] == "wide") if len(sys.argv) > 3 else False
 n = 256
 bad_total = 0
 for it in range(nconf):
