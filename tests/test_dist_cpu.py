@@ -232,6 +232,22 @@ def test_bench_self_launch_two_ranks(workload):
     assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["gather_ok"] is True
 
 
+def test_bench_rehearsal_single_batch_under_the_drivers_launcher():
+    """One batch in all (`--steps 1 --warmup 0`: the second table of the overlapped gather is never used), started the way the driver starts
+    N > 1 — `python -m torch.distributed.run` —, with the traces given as `--traces` (the launcher's parser claims a script option spelled
+    `--n` as an abbreviation of its own `--nnodes` / `--nproc-per-node` and exits)."""
+    import json, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--traces", "203",
+                        "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 1 and rec["gather_ok"] is True
+
+
 def test_bench_launcher_relays_failure():
     """a rank that exits non-zero (here: argparse rejects the workload in every child) makes the launcher exit non-zero"""
     import subprocess, sys
