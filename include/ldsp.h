@@ -74,6 +74,9 @@ const char* ldsp_last_error_string(void);
  * three traces per CU, for the standard geometry; the generic icpc_kernel, two
  * traces per CU, whenever CUSP and ZAC share their geometry and its LDS budget
  * allows).
+ * "icpc_generic" = 1 runs dsp_icpc on the generic icpc_kernel whatever the
+ * geometry (it keeps the eps * T term of the CUSP / ZAC last tap, see
+ * ldsp_icpc_run); "sipm_generic" = 1 likewise for dsp_sipm (k_sipm).
  * "dbg_stop" = k stops the kernels after phase k (profiling aid; outputs are
  * then incomplete). */
 int ldsp_ctx_set_option(ldsp_ctx* ctx, const char* key, int64_t value);
@@ -251,7 +254,14 @@ typedef struct {
 
 /* ---- fused routines ------------------------------------------------------ */
 
-/* dsp_icpc(data, config, tau, pars_filter)        src/dsp_icpc.jl:62-230 */
+/* dsp_icpc(data, config, tau, pars_filter)        src/dsp_icpc.jl:62-230
+ * Kernel choice and the one amplitude assumption behind it: the single-launch kernel (closed-form CUSP / ZAC) leaves out the
+ * eps * T term of those filters' last tap (eps = 1 - exp(-dt / tau_cusp): dsp_icpc sets that tau to 1e7 us "to switch off CR",
+ * src/dsp_icpc.jl:98).  The host admits it only where |w_last| * eps * A * L < 1e-2 with A = max(|sat_low|, |sat_high|, 65535):
+ * the SATURATION RAILS OF THE PARAMETER BLOCK (a 16-bit range when they are left at zero) are taken as the bound of the samples.
+ * float32 input is not clamped to them — traces far outside the configured rails get the dropped term's error scaled by their
+ * amplitude / A; option "icpc_generic" (ldsp_ctx_set_option) runs the kernel that keeps the term.  ldsp_ctx_last_kernel_name
+ * tells which kernel a call ran. */
 int ldsp_icpc_run(ldsp_ctx* ctx, const float* wf, int64_t n,
                   const ldsp_icpc_params* p, const ldsp_icpc_out* out);
 
