@@ -257,7 +257,7 @@ typedef struct {
 /* dsp_icpc(data, config, tau, pars_filter)        src/dsp_icpc.jl:62-230
  * Kernel choice and the one amplitude assumption behind it: the single-launch kernel (closed-form CUSP / ZAC) leaves out the
  * eps * T term of those filters' last tap (eps = 1 - exp(-dt / tau_cusp): dsp_icpc sets that tau to 1e7 us "to switch off CR",
- * src/dsp_icpc.jl:98).  The host admits it only where |w_last| * eps * A * L < 1e-2 with A = max(|sat_low|, |sat_high|, 65535):
+ * src/dsp_icpc.jl:98).  The host admits it only where |w_last| * eps * L < 1e-2 / 65535 (1.5e-7 of full scale A, A = max(|sat_low|, |sat_high|, 65535)):
  * the SATURATION RAILS OF THE PARAMETER BLOCK (a 16-bit range when they are left at zero) are taken as the bound of the samples.
  * float32 input is not clamped to them — traces far outside the configured rails get the dropped term's error scaled by their
  * amplitude / A; option "icpc_generic" (ldsp_ctx_set_option) runs the kernel that keeps the term.  ldsp_ctx_last_kernel_name

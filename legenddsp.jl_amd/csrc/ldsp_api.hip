@@ -448,7 +448,7 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, int r2, Ic
 // one pass each inside the same launch), the inverted t0 uses the same trapezoid, tx_mintot <= 2 samples, Savitzky-Golay windows
 // of at most 25 taps (the optimised one) / 13 taps (the two fixed ones), the chain of ZAC shifts with the parabola's last tap folded in exists (icpc_dev.hpp: zf_*), and the
 // eps * T term of the filters' last tap, which icpc_lean3 drops, is far below the columns' resolution: |w_last| * eps * rail * L
-// < 1e-2 on a trace that sits at the rail, a hundredth of that on a real one (dsp_icpc sets the filters' tau to 1e7 us,
+// < 1e-2 (for a 16-bit rail; the bound scales with the rail: 1.5e-7 of full scale) on a trace that sits at the rail, a hundredth of that on a real one (dsp_icpc sets the filters' tau to 1e7 us,
 // src/dsp_icpc.jl:98: 1.4e-3 for a 16-bit rail and 8192 samples).  ldsp_icpc_run and ldsp_icpc_pz_trap_run decide alike.
 // `full_tile`: only traces that fill the tile (config 2's lean kernel); the fused kernel also takes shorter traces of any length
 // (8000-, 7300-, 8190-, 7001-sample traces run it on the next tile up; when the length is no multiple of four samples the rows are
@@ -463,10 +463,15 @@ static bool icpc_lean_applies(const ldsp_ctx* c, bool full_tile = false) {
       H.cusp_mode != 1 || !H.t0inv_same || H.tx_mintot > 2 || H.sg_npts[0] > 25 || sg_fixed > 13)
     return false;
   // (the rails bound the signal; rails left at zero — saturation not configured — are taken as a 16-bit range, not as "no signal")
-  const double rail = std::max(std::max(std::fabs((double)H.sat_high), std::fabs((double)H.sat_low)), 65535.0) * (double)H.L;
+  const double amp = std::max(std::max(std::fabs((double)H.sat_high), std::fabs((double)H.sat_low)), 65535.0);
+  const double rail = amp * (double)H.L;
   const double drop = std::max(std::fabs((double)H.cusp.w_last) * H.cusp.eps, std::fabs((double)H.zac.w_last) * H.zac.eps) * rail;
   if (H.cz_shared && H.zac.zf_n <= 0) return false;
-  return drop < 1e-2 && icpc_lean3_smem_bytes(H.NT, std::max(H.cusp.Lf, H.zac.Lf)) <= 80640;   // (<= 53 760: three workgroups per CU)
+  // The bound scales with the rail: 1e-2 at a 16-bit range, i.e. 1.5e-7 of full scale — a quarter of a float32 ulp there.  Presummed
+  // traces (dsp_icpc_compressed: the upper rail times the presum rate, src/dsp_icpc.jl:339) carry the same physics at rate x the
+  // amplitude and rate x the sampling step; an absolute bound sent them to the generic kernel for a term the same size relative to
+  // their columns' float32 resolution.
+  return drop < 1e-2 * (amp / 65535.0) && icpc_lean3_smem_bytes(H.NT, std::max(H.cusp.Lf, H.zac.Lf)) <= 80640;   // (<= 53 760: three workgroups per CU)
 }
 
 static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p, int in_u16 = 0) {

@@ -115,6 +115,18 @@ def test_presummed_and_windowed_pair_rate4(orc):
         a, b = _np(res[rc]), ora[c]
         tol = 2e-3 if c == "t50" else 4 * parity.ATOL[c] + 4 * parity.RTOL * np.abs(b)
         assert (np.abs(a - b) > tol).sum() <= 1, (c, np.abs(a - b).max())
+    # the presummed pass runs the single-launch kernel: the admission bound of the dropped eps * T term scales with the rail (4 x 65520 here;
+    # an absolute bound sent these traces to the generic kernel until the end of round 4), and its whole table agrees with the generic
+    # kernel's, which keeps the term
+    ctx = ldsp.Context(0)
+    lean = ldsp.table_columns(ldsp.icpc_run(pre.signal, pa, ctx))
+    assert ctx.last_kernel_name() == "lean3::icpc_lean3_kernel"
+    ctx.set_option("icpc_generic", 1)
+    gen = ldsp.table_columns(ldsp.icpc_run(pre.signal, pa, ctx))
+    assert ctx.last_kernel_name() == "icpc_kernel"
+    for c in ("e_cusp", "e_zac", "e_cusp_max", "e_zac_max", "e_trap", "e_10410", "blmean"):
+        a, b = _np(lean[c]), _np(gen[c])
+        assert (np.abs(a - b) > 4 * parity.ATOL[c] + 4 * parity.RTOL * np.abs(b)).sum() == 0, (c, np.abs(a - b).max())
     # against the full-rate chain: same physics, a different sampling of it
     fused = ldsp.table_columns(ldsp.icpc_run(wf, ldsp.lower_icpc(cfg, tau, {}, L, 0.0, DT)))
     np.testing.assert_allclose(_np(res.blmean) / rate, _np(fused["blmean"]), rtol=1e-5)
