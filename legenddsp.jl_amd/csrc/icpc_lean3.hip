@@ -402,7 +402,7 @@ __device__ __forceinline__ uint32_t nib_le(f4 v, float t) {
 template <int NT, int M, bool SEP, bool FULL>
 __global__ void __launch_bounds__(NT, NT == 64 ? 5 : (FULL ? LDSP_L3_WPS : LDSP_L3_RWPS))   // (one-wave workgroups: 96 registers)
 icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, IcpcOutDev out, const float* __restrict__ ext_bl,
-                  float ext_bl_scale) {
+                  float ext_bl_scale, int skip_cz) {
   using SM = Smem<NT>;
   constexpr int NW = SM::NW, Lp = SM::Lp, NWORDS = SM::NWORDS;
   static_assert(R * NW <= 64, "wave-row partials must fit one wave");
@@ -2000,7 +2000,10 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
     }
   };
   using T_ = std::true_type; using F_ = std::false_type;
-  if constexpr (!SEP) {
+  if (skip_cz) {
+    // the windowed traces of dsp_icpc_compressed (dsp_icpc.jl:352-353 take no CUSP / ZAC column from them): the stage is left out
+    if (tid < 6) S.outv[tid < 3 ? (tid == 0 ? C_e_cusp : tid == 1 ? C_e_cusp_max : C_t_cusp_max) : (tid == 3 ? C_e_zac : tid == 4 ? C_e_zac_max : C_t_zac_max)] = NAN;
+  } else if constexpr (!SEP) {
     cz_pass(T_{}, T_{}, P.cusp, P.zac, S.misc[12]);
   } else {
     const float cp_c = S.misc[12], cp_z = S.misc[13];
@@ -2021,11 +2024,11 @@ icpc_lean3_kernel(const float* __restrict__ wf, const IcpcDev* __restrict__ Pp, 
 
 template <int NT, int M, bool SEP, bool FULL>
 static hipError_t launch_t(const float* wf, int64_t n, const IcpcDev* dP, const IcpcOutDev& out, const float* ext_bl, float ext_bl_scale,
-                           int Lf, hipStream_t st) {
+                           int Lf, bool skip_cz, hipStream_t st) {
   const size_t smem = Smem<NT>::bytes(cz_pad_floats(Lf)) + (size_t)g_dbg_lds_pad;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&icpc_lean3_kernel<NT, M, SEP, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((icpc_lean3_kernel<NT, M, SEP, FULL>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, out, ext_bl, ext_bl_scale);
+  hipLaunchKernelGGL((icpc_lean3_kernel<NT, M, SEP, FULL>), dim3((unsigned)n), dim3(NT), smem, st, wf, dP, out, ext_bl, ext_bl_scale, (int)skip_cz);
   return hipGetLastError();
 }
 
@@ -2045,13 +2048,13 @@ size_t icpc_lean3_smem_bytes(int NT, int Lf) {
 // sg_slots: 7, 13 or 25 (the smallest that holds the main Savitzky-Golay window; the two fixed ones have at most 13 taps)
 // full: the traces fill the tile (L = 16 NT); otherwise shorter traces (more than half the tile)
 hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, bool full, const IcpcDev* dP, const IcpcOutDev& out,
-                             const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st) {
+                             const float* ext_bl, float ext_bl_scale, int Lf, bool skip_cz, hipStream_t st) {
 #ifdef LDSP_DEV_512
 #define LDSP_LEAN_CASES LDSP_CASE(512)
 #else
 #define LDSP_LEAN_CASES LDSP_CASE(64) LDSP_CASE(128) LDSP_CASE(256) LDSP_CASE(512)
 #endif
-#define LDSP_ARGS wf, n, dP, out, ext_bl, ext_bl_scale, Lf, st
+#define LDSP_ARGS wf, n, dP, out, ext_bl, ext_bl_scale, Lf, skip_cz, st
 #define LDSP_CASE(N) \
   case N: \
     if (!full) return cz_shared ? (sg_slots <= 7 ? lean3::launch_t<N, 7, false, false>(LDSP_ARGS) : sg_slots <= 13 ? lean3::launch_t<N, 13, false, false>(LDSP_ARGS) : lean3::launch_t<N, 25, false, false>(LDSP_ARGS)) \

@@ -20,7 +20,7 @@ hipError_t launch_icpc(const float* wf, int64_t n, int NT, int R, bool full, con
                        const float* ext_bl, float ext_bl_scale, bool direct, bool cz_shared, bool fuse_ok, int stop_after_main, int cz_pad_floats, hipStream_t st, hipEvent_t mid,
                        int* stages);
 hipError_t launch_icpc_lean3(const float* wf, int64_t n, int NT, int sg_slots, bool cz_shared, bool full, const IcpcDev* dP, const IcpcOutDev& out,
-                             const float* ext_bl, float ext_bl_scale, int Lf, hipStream_t st);
+                             const float* ext_bl, float ext_bl_scale, int Lf, bool skip_cz, hipStream_t st);
 size_t icpc_lean3_smem_bytes(int NT, int Lf);
 extern int g_dbg_lds_pad;
 hipError_t launch_pz_trap_lean(const float* wf, int64_t n, int NT, bool u16, const IcpcDev* dP, float* blmean, float* e10410, hipStream_t st);
@@ -453,15 +453,18 @@ static int lower_icpc_dev(const ldsp_icpc_params& p, int cusp_direct, int r2, Ic
 // `full_tile`: only traces that fill the tile (config 2's lean kernel); the fused kernel also takes shorter traces of any length
 // (8000-, 7300-, 8190-, 7001-sample traces run it on the next tile up; when the length is no multiple of four samples the rows are
 // 4-byte aligned and the quad that holds the end of a trace is read sample by sample).
-static bool icpc_lean_applies(const ldsp_ctx* c, bool full_tile = false) {
+static bool icpc_lean_applies(const ldsp_ctx* c, bool full_tile = false, bool skip_cz = false) {
   const IcpcDev& H = c->icpc_host;
   // (Savitzky-Golay: the optimised window up to 25 taps — 350 ns at 16 ns, the end of the reference's scan grid, test/test_dsp_icpc.jl:134-138 —,
   // the two fixed windows, 60 and 100 ns, up to 13; a third filter equal to the first is not evaluated again)
   const int sg_fixed = std::max(H.sg_npts[1], H.sg_same_02 ? 0 : H.sg_npts[2]);
   if (c->icpc_generic || c->two_kernel || !(c->dbg_stop == 0 || c->dbg_stop >= 100) || H.R != 4 || H.L > 16 * H.NT || H.NT > 512 ||
       H.L <= 8 * H.NT || (full_tile && H.L != 16 * H.NT) ||   // (more than half the tile: its first two rows are in the trace)
-      H.cusp_mode != 1 || !H.t0inv_same || H.tx_mintot > 2 || H.sg_npts[0] > 25 || sg_fixed > 13)
+      (!skip_cz && H.cusp_mode != 1) || !H.t0inv_same || H.tx_mintot > 2 || H.sg_npts[0] > 25 || sg_fixed > 13)
     return false;
+  // (a call without the CUSP / ZAC stage — main_only, the windowed traces of dsp_icpc_compressed — leaves that stage's terms out: the form
+  // of its filters, the dropped eps * T term, the folded ZAC chain)
+  if (skip_cz) return icpc_lean3_smem_bytes(H.NT, 8) <= 80640;
   // (the rails bound the signal; rails left at zero — saturation not configured — are taken as a 16-bit range, not as "no signal")
   const double amp = std::max(std::max(std::fabs((double)H.sat_high), std::fabs((double)H.sat_low)), 65535.0);
   const double rail = amp * (double)H.L;
@@ -541,8 +544,10 @@ int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_
   // the lean kernel (icpc_lean3.hip) covers the standard geometry; everything else — and option "icpc_generic" — runs icpc_kernel
   const IcpcDev& H = c->icpc_host;
   const int sg_max = std::max(H.sg_npts[0], std::max(H.sg_npts[1], H.sg_npts[2]));
-  if (icpc_lean_applies(c) && !main_only) {
-    HIP_TRY(launch_icpc_lean3(wf, n, H.NT, sg_max, H.cz_shared != 0, H.L == 16 * H.NT, c->d_icpc, od, ext_bl, ext_bl_scale, std::max(H.cusp.Lf, H.zac.Lf), c->stream));
+  // (main_only — the windowed traces of dsp_icpc_compressed — runs the same kernel with its CUSP / ZAC stage skipped)
+  if (icpc_lean_applies(c, false, main_only)) {
+    HIP_TRY(launch_icpc_lean3(wf, n, H.NT, sg_max, main_only || H.cz_shared != 0, H.L == 16 * H.NT, c->d_icpc, od, ext_bl, ext_bl_scale,
+                              main_only ? 8 : std::max(H.cusp.Lf, H.zac.Lf), main_only, c->stream));
     c->last_kernel = "lean3::icpc_lean3_kernel";
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev1, c->stream)); c->n_launches = 1; c->n_stages = 1; }
     return LDSP_OK;

@@ -163,6 +163,22 @@ def test_fused_windowed_half_equals_functor_spelling(L_w, w0):
     for c in ("a_sg", "a_60", "a_100", "a_raw"):
         a, b = _np(f[c]), _np(u[c])
         assert (np.abs(a - b) > 1e-2 + 1e-4 * np.abs(b)).sum() <= 3, c
+    # where the single-launch kernel admits the window (it then runs with its CUSP / ZAC stage skipped), its columns are the generic
+    # kernel's within the chain's tolerances
+    ctx = ldsp.Context(0)
+    f2 = windowed_columns(wdw, bl_pre, rate, cfg, tau, {}, ctx)
+    k_default = ctx.last_kernel_name()
+    ctx.set_option("icpc_generic", 1)
+    g = windowed_columns(wdw, bl_pre, rate, cfg, tau, {}, ctx)
+    assert ctx.last_kernel_name() == "icpc_kernel"
+    if L_w == 3000:
+        assert k_default == "lean3::icpc_lean3_kernel"
+    for c in WINDOWED_COLS:
+        a, b = _np(f2[c]), _np(g[c])
+        assert np.array_equal(np.isnan(a), np.isnan(b)), (c, k_default)
+        ok = ~np.isnan(b)
+        tol = {"qdrift": 60, "lq": 60, "drift_time": 1.5}.get(c, 1e-2 if c.startswith("a_") else 2e-3)
+        assert (np.abs(a[ok] - b[ok]) > tol + 3e-4 * np.abs(b[ok])).sum() <= 1, (c, k_default, np.abs(a[ok] - b[ok]).max())
     # the context is back in its default state: a plain run afterwards is the plain chain
     p = ldsp.lower_icpc(cfg, tau, {}, L, 0.0, DT)
     t1 = ldsp.icpc_run(wf[:8].contiguous(), p)
