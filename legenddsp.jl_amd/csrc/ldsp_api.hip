@@ -532,6 +532,8 @@ int ldsp_icpc_run_opts(ldsp_ctx* c, const float* wf, int64_t n, const ldsp_icpc_
   static_assert(sizeof(ldsp_icpc_out) == sizeof(void*) * LDSP_ICPC_NCOLS + sizeof(int64_t), "ldsp_icpc_out layout");
   memcpy(od.col, out, sizeof(void*) * LDSP_ICPC_NCOLS);
   od.stride = out->stride > 0 ? out->stride : 1;
+  if (main_only)   // include/ldsp.h: the six CUSP / ZAC columns are not written by such a call, whichever kernel runs it
+    for (int col : {C_e_cusp, C_e_zac, C_e_cusp_max, C_e_zac_max, C_t_cusp_max, C_t_zac_max}) od.col[col] = nullptr;
   if (n > c->aux_cap) {  // grow-only workspace; steady-state calls do not allocate
     HIP_TRY(hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_aux);
