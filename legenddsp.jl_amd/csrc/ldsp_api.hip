@@ -82,6 +82,9 @@ static int ctx_build(ldsp_ctx* c) {
   HIP_TRY(hipMalloc(&c->d_icpc, sizeof(IcpcDev)));
   HIP_TRY(hipMalloc(&c->d_hc, sizeof(float) * LDSP_MAX_FIR_TAPS));
   HIP_TRY(hipMalloc(&c->d_hz, sizeof(float) * LDSP_MAX_FIR_TAPS));
+  HIP_TRY(hipMalloc(&c->d_icpc_b, sizeof(IcpcDev)));
+  HIP_TRY(hipMalloc(&c->d_hc_b, sizeof(float) * LDSP_MAX_FIR_TAPS));
+  HIP_TRY(hipMalloc(&c->d_hz_b, sizeof(float) * LDSP_MAX_FIR_TAPS));
   HIP_TRY(hipMalloc(&c->d_coef, sizeof(float) * LDSP_MAX_FIR_TAPS));
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
@@ -115,7 +118,7 @@ int ldsp_ctx_destroy(ldsp_ctx* c) {
   if (!c) return LDSP_OK;
   ldsp_device_guard guard(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_aux); (void)hipFree(c->d_coef); (void)hipFree(c->d_grid); (void)hipFree(c->d_fir_grid); (void)hipFree(c->d_sg_grid); (void)hipFree(c->d_sipm);
+  (void)hipFree(c->d_icpc); (void)hipFree(c->d_hc); (void)hipFree(c->d_hz); (void)hipFree(c->d_icpc_b); (void)hipFree(c->d_hc_b); (void)hipFree(c->d_hz_b); (void)hipFree(c->d_aux); (void)hipFree(c->d_coef); (void)hipFree(c->d_grid); (void)hipFree(c->d_fir_grid); (void)hipFree(c->d_sg_grid); (void)hipFree(c->d_sipm);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->evm) (void)hipEventDestroy(c->evm);
@@ -159,11 +162,11 @@ int ldsp_ctx_set_option(ldsp_ctx* c, const char* key, int64_t value) {
   if (!strcmp(key, "cusp_direct")) { c->cusp_direct = value != 0; return LDSP_OK; }
   if (!strcmp(key, "two_kernel")) { c->two_kernel = value != 0; return LDSP_OK; }
   if (!strcmp(key, "sipm_generic")) { c->sipm_generic = value != 0; return LDSP_OK; }
-  if (!strcmp(key, "dbg_stop")) { c->dbg_stop = (int)value; c->icpc_valid = false; return LDSP_OK; }
+  if (!strcmp(key, "dbg_stop")) { c->dbg_stop = (int)value; c->icpc_valid = c->icpc_valid_b = false; return LDSP_OK; }
   if (!strcmp(key, "dbg_lds_pad")) { ldsp::g_dbg_lds_pad = (int)value; return LDSP_OK; }
   if (!strcmp(key, "icpc_generic")) { c->icpc_generic = value != 0; return LDSP_OK; }
-  if (!strcmp(key, "icpc_r2")) { c->icpc_r2 = value != 0; c->icpc_valid = false; return LDSP_OK; }
-  if (!strcmp(key, "dbg_stamps")) { c->dbg_stamps = reinterpret_cast<long long*>((uintptr_t)value); c->icpc_valid = false; return LDSP_OK; }
+  if (!strcmp(key, "icpc_r2")) { c->icpc_r2 = value != 0; c->icpc_valid = c->icpc_valid_b = false; return LDSP_OK; }
+  if (!strcmp(key, "dbg_stamps")) { c->dbg_stamps = reinterpret_cast<long long*>((uintptr_t)value); c->icpc_valid = c->icpc_valid_b = false; return LDSP_OK; }
   if (!strcmp(key, "multi_serial")) { c->multi_serial = value != 0; return LDSP_OK; }
   if (!strcmp(key, "fir_grid_per_point")) { c->fir_grid_per_point = value != 0; return LDSP_OK; }
   return fail(LDSP_ERR_INVALID_ARG, "unknown option '%s'", key);
@@ -478,7 +481,17 @@ static bool icpc_lean_applies(const ldsp_ctx* c, bool full_tile = false, bool sk
 }
 
 static int prepare_icpc(ldsp_ctx* c, const ldsp_icpc_params* p, int in_u16 = 0) {
-  if (c->icpc_valid && c->icpc_mode_built == c->cusp_direct && c->icpc_u16_built == in_u16 && !memcmp(&c->icpc_last, p, sizeof *p)) return LDSP_OK;
+  auto current_matches = [&]() {
+    return c->icpc_valid && c->icpc_mode_built == c->cusp_direct && c->icpc_u16_built == in_u16 && !memcmp(&c->icpc_last, p, sizeof *p);
+  };
+  if (current_matches()) return LDSP_OK;
+  // the previous block becomes the current one (and is kept if a new one has to be built: the kernels of earlier calls read theirs in
+  // stream order, and a block is only ever written by stream-ordered copies)
+  std::swap(c->icpc_last, c->icpc_last_b); std::swap(c->icpc_valid, c->icpc_valid_b); std::swap(c->icpc_mode_built, c->icpc_mode_built_b);
+  std::swap(c->icpc_u16_built, c->icpc_u16_built_b); std::swap(c->icpc_host, c->icpc_host_b);
+  std::swap(c->d_icpc, c->d_icpc_b); std::swap(c->d_hc, c->d_hc_b); std::swap(c->d_hz, c->d_hz_b);
+  if (current_matches()) return LDSP_OK;
+  c->icpc_valid = false;
   std::vector<float> hc, hz;
   IcpcDev d;
   int rc = lower_icpc_dev(*p, c->cusp_direct, c->icpc_r2, d, hc, hz);

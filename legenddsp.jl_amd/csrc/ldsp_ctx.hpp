@@ -44,6 +44,16 @@ struct ldsp_ctx {
   ldsp::IcpcDev* d_icpc = nullptr;
   float* d_hc = nullptr;
   float* d_hz = nullptr;
+  // the parameter block used before the current one (a routine that alternates between two blocks — dsp_icpc_compressed: presummed and
+  // windowed traces — lowers and uploads each of them once)
+  ldsp_icpc_params icpc_last_b{};
+  bool icpc_valid_b = false;
+  int icpc_mode_built_b = -1;
+  int icpc_u16_built_b = -1;
+  ldsp::IcpcDev icpc_host_b{};
+  ldsp::IcpcDev* d_icpc_b = nullptr;
+  float* d_hc_b = nullptr;
+  float* d_hz_b = nullptr;
   float* d_aux = nullptr;   // [aux_cap][4] kernel 1 -> kernel 2 hand-over (blmean, t50 position)
   int64_t aux_cap = 0;
   float* d_fir_grid = nullptr;   // [fir_grid_cap] taps of ldsp_fir_grid_run (grow-only)
