@@ -507,3 +507,18 @@ def test_pz_trap_subchain_on_uint16_adc_counts(length, dt):
         np.testing.assert_allclose(b[0], full["blmean"].cpu().numpy(), rtol=2.5e-7)
     e_full = full["e_10410"].cpu().numpy().astype(np.float64)
     assert np.all(np.abs(b[1] - e_full) <= 0.02 + 3e-6 * np.abs(e_full)), np.abs(b[1] - e_full).max()
+
+
+def test_context_keeps_two_parameter_blocks():
+    """The context holds the previous parameter block beside the current one (ldsp_ctx.hpp): a caller alternating between two blocks
+    — dsp_icpc_compressed, presummed and windowed traces — gets the same tables as from fresh contexts, also after a third block has
+    taken a slot and after the slots have changed places several times."""
+    cfg = ldsp.reference_test_icpc_config()
+    wf = ldsp.synth.hpge_batch(64, L, device="cuda", seed=9)
+    blocks = [ldsp.lower_icpc(cfg, tau * ldsp.us, {}, L, 0.0, 16.0) for tau in (500, 300, 420)]
+    fresh = [ldsp.icpc_run(wf, b, ldsp.Context(0)).clone() for b in blocks]
+    ctx = ldsp.Context(0)
+    for i in (0, 1, 0, 1, 2, 1, 0, 2, 2, 0):
+        t = ldsp.icpc_run(wf, blocks[i], ctx)
+        assert torch.equal(torch.nan_to_num(t, nan=-1.0), torch.nan_to_num(fresh[i], nan=-1.0)), i
+    assert not torch.equal(torch.nan_to_num(fresh[0], nan=-1.0), torch.nan_to_num(fresh[1], nan=-1.0))
