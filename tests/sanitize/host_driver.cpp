@@ -15,7 +15,7 @@
 namespace ldsp {
 hipError_t launch_icpc(const float*, int64_t, int, int, bool, const IcpcDev*, float*, const IcpcOutDev&, const float*, float, bool, bool, bool, int, int,
                        hipStream_t, hipEvent_t, int*) { return hipErrorNotSupported; }
-hipError_t launch_icpc_lean3(const float*, int64_t, int, int, bool, bool, const IcpcDev*, const IcpcOutDev&, const float*, float, int, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_icpc_lean3(const float*, int64_t, int, int, bool, bool, const IcpcDev*, const IcpcOutDev&, const float*, float, int, bool, hipStream_t) { return hipErrorNotSupported; }
 size_t icpc_lean3_smem_bytes(int NT, int Lf) { return (size_t)(NT * 16 + Lf) * 4; }
 int g_dbg_lds_pad = 0;
 hipError_t launch_pz_trap_lean(const float*, int64_t, int, bool, const IcpcDev*, float*, float*, hipStream_t) { return hipErrorNotSupported; }
